@@ -1,0 +1,192 @@
+"""Generate tests/golden/*.npz by running the reference's own primitives.
+
+TEST INFRASTRUCTURE.  Run in a container where /root/reference is mounted:
+
+    python oracle/make_golden.py
+
+The reference imports cv2 and torchvision at module top (model.py:9,11-13,
+utils.py:2,4-5,16) for drawing helpers only; neither is installed here, so
+empty stand-in modules are registered before the import.  No tensor code path
+touches them.  YOLOv1 is instantiated without its backbone (``__new__`` + the
+attributes ``__init__`` sets, model.py:107-114) -- the head methods use nothing
+else.
+
+Fixtures (inputs AND the reference's outputs; data only):
+  g1_iou.npz        eval.get_area / get_intersection_area / get_iou
+  g2_decode.npz     YOLOv1.get_norm_xywh, denormalize_xywh, xywh_to_ltrb
+  g3_head.npz       get_confidence, get_classification_prob,
+                    get_confidence_mask, _get_classification_index
+  g4_objmask.npz    get_object_mask
+  g5_targets.npz    VOC2012Dataset.ltrb_to_xywh / normalize_xywh
+  g6_terms.npz      reference get_coordinate_loss / get_classification_loss run
+                    with two documented patches (see below)
+  g7_oracle_cfg1.npz  NOT from the reference: the oracle's own outputs at
+                    config 1 (batch 16), kept as a regression vector and as the
+                    input/expected pair the GPU tests replay.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("YOLO_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _import_reference():
+    for name in ("cv2", "torchvision", "torchvision.utils", "torchvision.transforms",
+                 "torchvision.transforms.functional"):
+        if name not in sys.modules:
+            mod = types.ModuleType(name)
+            mod.__path__ = []  # mark as package so submodule imports resolve
+            sys.modules[name] = mod
+    sys.modules["torchvision.utils"].draw_bounding_boxes = None
+    sys.modules["torchvision.utils"].make_grid = None
+    sys.modules["torchvision"].utils = sys.modules["torchvision.utils"]
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
+    sys.path.insert(0, REF)
+    import eval as ref_eval      # noqa: E402
+    import model as ref_model    # noqa: E402
+    import data as ref_data      # noqa: E402
+    return ref_eval, ref_model, ref_data
+
+
+def _bare_head(ref_model, img_size=448, n_cells=7, n_bboxes=2, n_classes=20):
+    m = ref_model.YOLOv1.__new__(ref_model.YOLOv1)
+    torch.nn.Module.__init__(m)
+    m.img_size, m.n_cells, m.n_bboxes, m.n_classes = img_size, n_cells, n_bboxes, n_classes
+    m.coord_coeff, m.noobj_coeff = 5, 0.5
+    m.cell_size = img_size // n_cells
+    return m
+
+
+def _boxes(gen, n, img=448.0):
+    a = torch.rand(n, 2, generator=gen) * img
+    b = torch.rand(n, 2, generator=gen) * img
+    lt = torch.minimum(a, b)
+    rb = torch.maximum(a, b)
+    return torch.cat([lt, rb], dim=1)
+
+
+def main():
+    ref_eval, ref_model, ref_data = _import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    sys.path.insert(0, ROOT)
+    from oracle import ref_cpu
+    from yolo_amd import synth
+
+    # ---- G1: box geometry -------------------------------------------------
+    gen = torch.Generator().manual_seed(101)
+    b1 = _boxes(gen, 98)
+    b2 = _boxes(gen, 98)
+    # degenerate rows: zero area, inverted, identical, touching, nested
+    b1[0] = torch.tensor([10., 10., 10., 50.]);   b2[0] = torch.tensor([10., 10., 10., 50.])
+    b1[1] = torch.tensor([50., 50., 20., 20.]);   b2[1] = torch.tensor([0., 0., 100., 100.])
+    b1[2] = torch.tensor([5., 5., 25., 25.]);     b2[2] = torch.tensor([5., 5., 25., 25.])
+    b1[3] = torch.tensor([0., 0., 10., 10.]);     b2[3] = torch.tensor([10., 0., 20., 10.])
+    b1[4] = torch.tensor([0., 0., 100., 100.]);   b2[4] = torch.tensor([25., 25., 75., 75.])
+    b1[5] = torch.tensor([0., 0., 0., 0.]);       b2[5] = torch.tensor([0., 0., 0., 0.])
+    b1[6] = torch.tensor([0., 0., 448., 448.]);   b2[6] = torch.tensor([0., 0., 448., 448.])
+    np.savez(
+        os.path.join(OUT, "g1_iou.npz"),
+        ltrb1=b1.numpy(), ltrb2=b2.numpy(),
+        area1=ref_eval.get_area(b1).numpy(), area2=ref_eval.get_area(b2).numpy(),
+        inter=ref_eval.get_intersection_area(b1, b2).numpy(),
+        iou=ref_eval.get_iou(b1, b2).numpy(),
+    )
+
+    # ---- G2: decode -------------------------------------------------------
+    head = _bare_head(ref_model)
+    gen = torch.Generator().manual_seed(102)
+    pred_img = torch.randn(30, 7, 7, generator=gen) * 2
+    norm_boxmajor = head.get_norm_xywh(pred_img)                  # (98,4), box-major cat
+    norm_cellmajor = torch.rand(98, 4, generator=gen)             # row = cell*2 + k
+    norm_cellmajor[0] = 1.0
+    norm_cellmajor[97] = 0.0
+    denorm = head.denormalize_xywh(norm_cellmajor)
+    ltrb = head.xywh_to_ltrb(denorm)
+    extra_xywh = torch.tensor([[-50., -50., 20., 20.], [500., 500., 10., 10.],
+                               [224., 224., 1000., 1000.], [0., 0., 0., 0.]])
+    np.savez(
+        os.path.join(OUT, "g2_decode.npz"),
+        pred_img=pred_img.numpy(), norm_boxmajor=norm_boxmajor.numpy(),
+        norm_cellmajor=norm_cellmajor.numpy(), denorm=denorm.numpy(), ltrb=ltrb.numpy(),
+        extra_xywh=extra_xywh.numpy(), extra_ltrb=head.xywh_to_ltrb(extra_xywh).numpy(),
+    )
+
+    # ---- G3: batched head primitives ---------------------------------------
+    gen = torch.Generator().manual_seed(103)
+    out = torch.randn(16, 30, 7, 7, generator=gen) * 2
+    np.savez(
+        os.path.join(OUT, "g3_head.npz"),
+        out=out.numpy(),
+        conf=head.get_confidence(out).numpy(),
+        cls_prob=head.get_classification_prob(out).numpy(),
+        conf_mask_050=head.get_confidence_mask(out, conf_thresh=0.5).numpy(),
+        conf_mask_090=head.get_confidence_mask(out, conf_thresh=0.9).numpy(),
+        cls_idx=head._get_classification_index(out).numpy(),
+    )
+
+    # ---- G4: object mask ----------------------------------------------------
+    gen = torch.Generator().manual_seed(104)
+    gts, masks = [], []
+    for n in (1, 3, 5, 8):
+        gt = _boxes(gen, n, img=447.0)
+        gts.append(gt)
+        masks.append(head.get_object_mask(gt))
+    gt_pad = torch.zeros(len(gts), 8, 4)
+    cnt = torch.zeros(len(gts), dtype=torch.long)
+    for i, g in enumerate(gts):
+        gt_pad[i, : g.shape[0]] = g
+        cnt[i] = g.shape[0]
+    np.savez(os.path.join(OUT, "g4_objmask.npz"), gt_ltrb=gt_pad.numpy(), count=cnt.numpy(),
+             mask=torch.stack(masks).numpy())
+
+    # ---- G5: target normalisation -------------------------------------------
+    ds = ref_data.VOC2012Dataset.__new__(ref_data.VOC2012Dataset)
+    ds.img_size, ds.n_cells, ds.cell_size = 448, 7, 64
+    gen = torch.Generator().manual_seed(105)
+    gt = torch.round(_boxes(gen, 64, img=447.0))
+    xywh = ref_data.VOC2012Dataset.ltrb_to_xywh(gt)
+    np.savez(os.path.join(OUT, "g5_targets.npz"), ltrb=gt.numpy(), xywh=xywh.numpy(),
+             norm=ds.normalize_xywh(xywh).numpy())
+
+    # ---- G6: two loss terms through the reference's own code ----------------
+    # Patch 1 (repair R1): get_norm_xywh is replaced by its batched form, because the
+    #   reference's version accepts one image only (model.py:158-165) while
+    #   get_coordinate_loss indexes a 4-D result (model.py:226).
+    # Patch 2 (repair R5): get_classification_loss reads a module-level name
+    #   ``obj_mask`` (model.py:291); it is injected into the module's globals.
+    pred, gx, gc, om = synth.make_inputs(16, seed=0)
+    _, _, _, resp = ref_cpu.loss_terms(pred, gx, gc, om)
+    head.get_norm_xywh = lambda o: ref_cpu.get_norm_xywh(o, 2)
+    ref_coord = head.get_coordinate_loss(pred, gt_norm_xywh=gx, resp_mask=resp)
+    ref_model.obj_mask = om
+    ref_cls = head.get_classification_loss(pred, gt_cls_prob=gc)
+    np.savez(os.path.join(OUT, "g6_terms.npz"), pred=pred.numpy(), gt_norm_xywh=gx.numpy(),
+             gt_cls_prob=gc.numpy(), obj_mask=om.numpy(), resp_mask=resp.numpy(),
+             coord=ref_coord.numpy(), cls=ref_cls.numpy())
+
+    # ---- G7: oracle regression vector at config 1 (NOT reference output) ----
+    res = ref_cpu.loss_and_grad(pred, gx, gc, om)
+    dets, count, keep_idx = ref_cpu.postprocess(pred, conf_thresh=0.5, iou_thresh=0.5, mode=0)
+    dets1, count1, keep_idx1 = ref_cpu.postprocess(pred, conf_thresh=0.1, iou_thresh=0.3, mode=1)
+    np.savez(
+        os.path.join(OUT, "g7_oracle_cfg1.npz"),
+        coord=res["coord"].numpy(), conf=res["conf"].numpy(), cls=res["cls"].numpy(),
+        total=res["total"].numpy(), loss=res["loss"].numpy(), grad=res["grad"].numpy(),
+        dets_mode0=dets, count_mode0=count, keep_idx_mode0=keep_idx,
+        dets_mode1=dets1, count_mode1=count1, keep_idx_mode1=keep_idx1,
+    )
+    print("wrote", sorted(os.listdir(OUT)))
+
+
+if __name__ == "__main__":
+    main()
