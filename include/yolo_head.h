@@ -1,0 +1,158 @@
+/*
+ * libyolohead -- C ABI of the MI355X (gfx950) YOLOv1 detection head.
+ *
+ * The reference (KimRass/YOLO) has no FFI or operator interface: its head is a
+ * set of Python methods on YOLOv1 (model.py:150-317, 379-394) built from
+ * eval.py:14-65.  Each entry point below names the reference methods it
+ * replaces.  All pointers are DEVICE pointers to contiguous buffers owned by
+ * the caller; the library allocates nothing, keeps no state and never
+ * synchronises: every call only enqueues kernels on `stream` (a hipStream_t
+ * passed as void*; NULL = the default stream) for the current device.
+ *
+ * Return value: 0 = ok; < 0 = argument error found on the host before anything
+ * was launched (YH_ERR_*); > 0 = the hipError_t of a failed launch.
+ * yh_strerror() describes either kind.
+ *
+ * Tensor layouts (fp32 unless stated; S = grid size, Bx = predictors per cell,
+ * C = classes, D = 5*Bx + C):
+ *   pred      (batch, D, S, S)    raw logits, channel-major (model.py:140-148):
+ *                                 ch 5k..5k+3 = x,y,w,h of predictor k,
+ *                                 ch 5k+4 = its confidence, ch 5Bx.. = classes
+ *   cell index                    i*S + j for pred[b, :, i, j]; the FIRST
+ *                                 spatial axis carries x (model.py:171-180)
+ *   gt_xywh   (batch, S*S, 1, 4)  normalised ground truth (data.py:185-194)
+ *   gt_cls    (batch, S*S, 1, C)  class probabilities
+ *   obj_mask  (batch, S*S, 1, 1)  uint8 / bool
+ */
+#ifndef YOLO_HEAD_H
+#define YOLO_HEAD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YH_VERSION 100 /* 0.1.0 */
+
+#define YH_OK 0
+#define YH_ERR_NULL (-1)        /* a required pointer is NULL */
+#define YH_ERR_SHAPE (-2)       /* batch/S/Bx/C/img_size outside the supported range */
+#define YH_ERR_WORKSPACE (-3)   /* workspace missing or smaller than yh_workspace_bytes() */
+#define YH_ERR_ALIGN (-4)       /* a pointer is not aligned as documented */
+#define YH_ERR_ARG (-5)         /* a scalar argument is invalid (mode, threshold is NaN, ...) */
+#define YH_ERR_UNSUPPORTED (-6) /* more candidates per image than the kernels handle */
+
+/* limits checked on the host */
+#define YH_MAX_S 64
+#define YH_MAX_BX 16
+#define YH_MAX_C 4096
+#define YH_MAX_CANDIDATES 1024 /* per image, for the NMS entry points */
+
+/* op codes for yh_workspace_bytes */
+#define YH_OP_LOSS 0
+#define YH_OP_DECODE_NMS 1
+#define YH_OP_DECODE_GRID 2
+#define YH_OP_NMS 3
+
+/* candidate modes of the NMS entry points */
+#define YH_MODE_REFERENCE 0 /* per cell the higher-confidence predictor (model.py:384-390) */
+#define YH_MODE_DENSE 1     /* every predictor of every cell */
+
+int yh_version(void);
+const char* yh_strerror(int rc);
+
+/* Bytes of device workspace the op needs for this shape (0 if none). */
+size_t yh_workspace_bytes(int op, int64_t batch, int S, int Bx, int C);
+
+/*
+ * Loss forward + backward in one pass.  Replaces YOLOv1.get_loss and everything
+ * it calls (model.py:296-317: _get_responsibility_mask :190-211,
+ * get_coordinate_loss :224-240, get_confidence_loss :252-276,
+ * get_classification_loss :288-294, get_ltrb :185-188, eval.get_iou
+ * eval.py:53-65) and the autograd backward of loss.backward() (train.py:89,93).
+ *
+ * grad_pred (batch, D, S, S) receives d(total * inv_global_batch)/d(pred).
+ * loss_terms[5] receives: coordinate, confidence and class SUMS over this
+ * batch (not divided), their total, and total * inv_global_batch (the value
+ * get_loss returns when inv_global_batch = 1/batch, model.py:317).
+ * Alignment: gt_xywh 16 bytes; gt_cls 16 bytes when C % 4 == 0.
+ * workspace: yh_workspace_bytes(YH_OP_LOSS, ...) bytes, 16-byte aligned.
+ * The result is bitwise reproducible from run to run (no float atomics).
+ */
+int yh_loss_fwd_bwd(const float* pred, const float* gt_xywh, const float* gt_cls,
+                    const uint8_t* obj_mask, float* grad_pred, float* loss_terms,
+                    void* workspace, size_t workspace_bytes, int64_t batch, int S, int Bx,
+                    int C, int img_size, float lambda_coord, float lambda_noobj,
+                    float inv_global_batch, void* stream);
+
+/*
+ * grad[i] *= *scale for i < n, in place; does not touch memory when *scale == 1.
+ * `scale` is a device scalar: the grad_output that reaches the head's backward
+ * (1 for loss.backward(), the GradScaler scale for
+ * scaler.scale(loss).backward(), train.py:89).
+ */
+int yh_scale_grad(float* grad, const float* scale, int64_t n, void* stream);
+
+/*
+ * Dense grid decode.  Replaces get_ltrb (model.py:150-188), get_confidence
+ * (:242-250), get_classification_prob (:278-286), _get_classification_index
+ * (:392-394), get_confidence_mask (:379-382) and get_max_confidence_ltrb
+ * (:384-390).  Every output pointer may be NULL (that output is skipped).
+ *   ltrb      (batch, S*S, Bx, 4)  pixels, one-sided clips as xywh_to_ltrb
+ *   conf      (batch, S*S, Bx, 1)
+ *   cls_prob  (batch, S*S, 1, C)   softmax
+ *   cls_idx   (batch, S*S, 1, 1)   int64, argmax of the class logits, first index on ties
+ *   best_k    (batch, S*S, 1, 1)   int64, predictor with the higher confidence, first on ties
+ *   best_ltrb (batch, S*S, 1, 4)
+ *   conf_mask (batch, S*S, 1, 1)   uint8, max_k conf >= conf_thresh
+ */
+int yh_decode_grid(const float* pred, float* ltrb, float* conf, float* cls_prob,
+                   int64_t* cls_idx, int64_t* best_k, float* best_ltrb, uint8_t* conf_mask,
+                   float conf_thresh, int64_t batch, int S, int Bx, int C, int img_size,
+                   void* stream);
+
+/*
+ * NMS candidates exactly as yh_decode_nms forms them internally (same device
+ * code): flat index n = cell*Bx + k, N = S*S*Bx per image.
+ *   cand_ltrb (batch, N, 4), cand_score (batch, N) = confidence,
+ *   cand_cls (batch, N) int32 = class of the cell, cand_present (batch, N) uint8
+ *   (mode YH_MODE_REFERENCE: only the higher-confidence predictor of a cell is
+ *   present; YH_MODE_DENSE: all are).
+ */
+int yh_decode_candidates(const float* pred, float* cand_ltrb, float* cand_score,
+                         int32_t* cand_cls, uint8_t* cand_present, int mode, int64_t batch,
+                         int S, int Bx, int C, int img_size, void* stream);
+
+/*
+ * Fused decode + confidence threshold + per-class greedy NMS.  The reference
+ * stops at the confidence threshold (model.py:379-394, 406-419) and has no
+ * NMS; the keep rule is specified here: a candidate is valid when present and
+ * score >= conf_thresh; valid candidates are ordered by class ascending, score
+ * descending, flat index ascending; walking each class in that order a
+ * candidate is kept unless an already kept one of its class has
+ * IoU > iou_thresh with it (IoU arithmetic of eval.py:53-65 in fp32).
+ *   dets       (batch, N, 6)  kept rows l,t,r,b,score,class (the layout
+ *              eval.py:89-91 consumes) in that order, zero rows after them
+ *   keep_count (batch) int32
+ *   keep_idx   (batch, N) int32 flat index of each kept row, -1 after them; may be NULL
+ * N = S*S*Bx <= YH_MAX_CANDIDATES.
+ */
+int yh_decode_nms(const float* pred, float* dets, int32_t* keep_count, int32_t* keep_idx,
+                  int mode, float conf_thresh, float iou_thresh, int64_t batch, int S, int Bx,
+                  int C, int img_size, void* stream);
+
+/*
+ * The same NMS over caller-supplied candidates (N per image, any order; the
+ * flat index is the position in the input).  cand_present may be NULL (all
+ * present).  Classes must be in [0, 32767].
+ */
+int yh_nms(const float* cand_ltrb, const float* cand_score, const int32_t* cand_cls,
+           const uint8_t* cand_present, float* dets, int32_t* keep_count, int32_t* keep_idx,
+           float conf_thresh, float iou_thresh, int64_t batch, int N, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO_HEAD_H */

@@ -1,0 +1,212 @@
+"""HIP loss forward+backward against the CPU oracle (oracle/ref_cpu.py), through
+the C ABI.  Tolerance: the target is 1e-5 relative in fp32.  Scalars (the three
+term sums, the total, the loss) are compared at rtol 1e-5.  The gradient is
+compared with max|hip - oracle| <= 1e-5 * max|oracle| -- relative to the
+tensor's scale, because single elements are differences of nearly equal terms
+(conf - IoU) whose own fp32 rounding in the oracle is already ~1e-7 absolute."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu
+from yolo_amd import YOLOv1Head, synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def run_hip(head, dev, pred, gx, gc, om, global_batch=None):
+    terms, grad = head.loss_fwd_bwd(pred.to(dev), gx.to(dev), gc.to(dev), om.to(dev),
+                                    global_batch=global_batch)
+    torch.cuda.synchronize()
+    return terms.cpu(), grad.cpu()
+
+
+def check_against_oracle(terms, grad, ref, rtol=RTOL):
+    for i, name in enumerate(("coord", "conf", "cls", "total", "loss")):
+        want = ref[name].item()
+        got = terms[i].item()
+        assert abs(got - want) <= rtol * max(abs(want), 1e-30), (name, got, want)
+    scale = ref["grad"].abs().max().item()
+    err = (grad - ref["grad"]).abs().max().item()
+    assert err <= rtol * scale, (err, scale)
+
+
+def hp_of(head):
+    return dict(n_cells=head.n_cells, n_bboxes=head.n_bboxes, n_classes=head.n_classes,
+                img_size=head.img_size, coord_coeff=head.coord_coeff, noobj_coeff=head.noobj_coeff)
+
+
+def test_config1_matches_oracle_and_golden(dev, golden):
+    head = YOLOv1Head()
+    pred, gx, gc, om = synth.make_inputs(16, seed=0)
+    terms, grad = run_hip(head, dev, pred, gx, gc, om)
+    ref = ref_cpu.loss_and_grad(pred, gx, gc, om)
+    check_against_oracle(terms, grad, ref)
+    g = golden("g7_oracle_cfg1.npz")
+    assert abs(terms[4].item() - float(g["loss"])) <= RTOL * abs(float(g["loss"]))
+    gg = torch.from_numpy(g["grad"])
+    assert (grad - gg).abs().max().item() <= RTOL * gg.abs().max().item()
+    # the two terms that the reference's own code produced (golden g6)
+    t6 = golden("g6_terms.npz")
+    assert abs(terms[0].item() - float(t6["coord"])) <= RTOL * float(t6["coord"])
+    assert abs(terms[2].item() - float(t6["cls"])) <= RTOL * float(t6["cls"])
+
+
+def test_fp64_oracle_agrees(dev):
+    head = YOLOv1Head()
+    pred, gx, gc, om = synth.make_inputs(64, seed=3)
+    terms, grad = run_hip(head, dev, pred, gx, gc, om)
+    ref = ref_cpu.loss_and_grad(pred, gx, gc, om, dtype=torch.float64)
+    assert abs(terms[4].item() - ref["loss"].item()) <= RTOL * abs(ref["loss"].item())
+    scale = ref["grad"].abs().max().item()
+    assert (grad.double() - ref["grad"]).abs().max().item() <= RTOL * scale
+
+
+@pytest.mark.parametrize("batch", [1, 4, 5, 6, 7, 13, 33, 257])
+def test_ragged_batches(dev, batch):
+    head = YOLOv1Head()
+    pred, gx, gc, om = synth.make_inputs(batch, seed=10 + batch)
+    terms, grad = run_hip(head, dev, pred, gx, gc, om)
+    check_against_oracle(terms, grad, ref_cpu.loss_and_grad(pred, gx, gc, om))
+
+
+def test_no_objects_and_all_objects(dev):
+    head = YOLOv1Head()
+    pred, gx, gc, om = synth.make_inputs(8, seed=21)
+    none = torch.zeros_like(om)
+    terms, grad = run_hip(head, dev, pred, gx, gc, none)
+    ref = ref_cpu.loss_and_grad(pred, gx, gc, none)
+    check_against_oracle(terms, grad, ref)
+    assert terms[0].item() == 0 and terms[2].item() == 0
+    # every cell holds an object
+    g = torch.Generator().manual_seed(5)
+    gx_all = torch.rand(8, 49, 1, 4, generator=g) * 0.9 + 0.05
+    lab = torch.randint(0, 20, (8, 49), generator=g)
+    gc_all = torch.nn.functional.one_hot(lab, 20).float().view(8, 49, 1, 20)
+    om_all = torch.ones(8, 49, 1, 1, dtype=torch.bool)
+    terms, grad = run_hip(head, dev, pred, gx_all, gc_all, om_all)
+    check_against_oracle(terms, grad, ref_cpu.loss_and_grad(pred, gx_all, gc_all, om_all))
+
+
+@pytest.mark.parametrize("S,Bx,C,img,batch", [
+    (14, 5, 80, 448, 3),     # the NMS stress shape also runs through the loss
+    (3, 1, 4, 96, 9),
+    (7, 3, 20, 448, 6),
+    (7, 2, 21, 448, 5),      # class count not a multiple of 4
+    (17, 2, 5, 34 * 17, 2),  # more cells than threads in a workgroup
+])
+def test_other_shapes(dev, S, Bx, C, img, batch):
+    head = YOLOv1Head(img_size=img, n_cells=S, n_bboxes=Bx, n_classes=C)
+    pred, gx, gc, om = synth.make_inputs(batch, S, Bx, C, img, seed=40 + S)
+    terms, grad = run_hip(head, dev, pred, gx, gc, om)
+    check_against_oracle(terms, grad, ref_cpu.loss_and_grad(pred, gx, gc, om, **hp_of(head)))
+
+
+def test_other_coefficients(dev):
+    head = YOLOv1Head(coord_coeff=2.5, noobj_coeff=0.25)
+    pred, gx, gc, om = synth.make_inputs(12, seed=8)
+    terms, grad = run_hip(head, dev, pred, gx, gc, om)
+    check_against_oracle(terms, grad, ref_cpu.loss_and_grad(pred, gx, gc, om, **hp_of(head)))
+
+
+def test_extreme_logits_and_degenerate_boxes(dev):
+    """Saturated sigmoids, boxes clipped at the image border on every side, a
+    ground-truth box of zero size, and a prediction equal to the ground truth."""
+    head = YOLOv1Head()
+    pred, gx, gc, om = synth.make_inputs(8, seed=77)
+    pred[0] = pred[0] * 6.0                       # |logit| up to ~50: sigmoid saturates
+    pred[1, 0:4] = -12.0                          # tiny boxes in the cell corner
+    pred[2, 2:4] = 12.0                           # boxes as large as the image: all four clips
+    gx[3, :, 0, 2:4] = 0.0                        # zero-size ground truth where present
+    cells = om[4, :, 0, 0].nonzero()[:, 0]
+    for c in cells.tolist():                      # predictor 0 reproduces the ground truth
+        g = gx[4, c, 0].clamp(1e-4, 1 - 1e-4)
+        pred[4, 0:4, c // 7, c % 7] = torch.log(g / (1 - g))
+    terms, grad = run_hip(head, dev, pred, gx, gc, om)
+    assert torch.isfinite(grad).all() and torch.isfinite(terms).all()
+    check_against_oracle(terms, grad, ref_cpu.loss_and_grad(pred, gx, gc, om))
+
+
+def test_full_size_batch_4096(dev):
+    head = YOLOv1Head()
+    pred, gx, gc, om = synth.make_inputs(4096, seed=0)
+    dp, dx, dc, dm = pred.to(dev), gx.to(dev), gc.to(dev), om.to(dev)
+    terms, grad = head.loss_fwd_bwd(dp, dx, dc, dm)
+    terms2, grad2 = head.loss_fwd_bwd(dp, dx, dc, dm)
+    torch.cuda.synchronize()
+    # reproducible bit for bit
+    assert torch.equal(terms, terms2) and torch.equal(grad, grad2)
+    # the oracle still finishes in seconds at this size
+    check_against_oracle(terms.cpu(), grad.cpu(), ref_cpu.loss_and_grad(pred, gx, gc, om))
+    # sharding by image: shard gradients are slices of the full gradient (bit-exact),
+    # shard sums add up to the full sums
+    acc = torch.zeros(5, dtype=torch.float64)
+    for lo, hi in ((0, 1000), (1000, 1003), (1003, 4096)):
+        t, g = head.loss_fwd_bwd(dp[lo:hi], dx[lo:hi], dc[lo:hi], dm[lo:hi], global_batch=4096)
+        assert torch.equal(g, grad[lo:hi])
+        acc += t.double().cpu()
+    assert torch.allclose(acc[:4], terms[:4].double().cpu(), rtol=1e-6, atol=0)
+    assert abs(acc[4].item() - terms[4].item()) <= 1e-6 * abs(terms[4].item())
+    # cells without an object get exactly zero box and class gradients
+    noobj = ~om[:, :, 0, 0].view(4096, 7, 7)
+    gcpu = grad.cpu()
+    for ch in (0, 1, 2, 3, 5, 6, 7, 8) + tuple(range(10, 30)):
+        assert gcpu[:, ch][noobj].abs().max().item() == 0.0
+    # 1/B enters linearly
+    t8, g8 = head.loss_fwd_bwd(dp, dx, dc, dm, global_batch=8 * 4096)
+    assert torch.equal(g8 * 8, grad)
+
+
+def test_autograd_path_and_grad_scaler(dev):
+    head = YOLOv1Head()
+    pred, gx, gc, om = synth.make_inputs(16, seed=0)
+    dx, dc, dm = gx.to(dev), gc.to(dev), om.to(dev)
+    _, want = head.loss_fwd_bwd(pred.to(dev), dx, dc, dm)
+
+    out = pred.to(dev).requires_grad_(True)
+    loss = head.get_loss(out, dx, dc, dm)
+    assert loss.dim() == 0 and loss.requires_grad
+    loss.backward()
+    assert torch.equal(out.grad, want)
+    assert torch.equal(head.last_loss_terms[4], loss.detach())
+
+    # the GradScaler path of train.py:88-91: grad_output is the scale, not 1
+    out2 = pred.to(dev).requires_grad_(True)
+    loss2 = head.get_loss(out2, dx, dc, dm)
+    (loss2 * 65536.0).backward()
+    assert torch.equal(out2.grad, want * 65536.0)
+
+    # gradient reaches a producer of the head tensor
+    w = torch.ones(1, 30, 1, 1, device=dev, requires_grad=True)
+    head.get_loss(pred.to(dev) * w, dx, dc, dm).backward()
+    torch.testing.assert_close(w.grad.view(-1), (want * pred.to(dev)).sum(dim=(0, 2, 3)),
+                               rtol=1e-4, atol=1e-6)
+
+    # no graph under no_grad / for a tensor that needs no gradient
+    with torch.no_grad():
+        l3 = head.get_loss(out, dx, dc, dm)
+    assert not l3.requires_grad and torch.equal(l3, loss.detach())
+
+
+def test_backbone_hook_and_call_shape(dev):
+    """get_loss(image, ...) as train.py intends: the image goes through the model."""
+    lin = torch.nn.Linear(12, 30 * 49).to(dev)
+    head = YOLOv1Head(backbone=lin)
+    _, gx, gc, om = synth.make_inputs(4, seed=2)
+    image = torch.randn(4, 12, device=dev)
+    loss = head.get_loss(image, gx.to(dev), gc.to(dev), om.to(dev))
+    loss.backward()
+    assert lin.weight.grad is not None and torch.isfinite(lin.weight.grad).all()
+    ref = ref_cpu.get_loss(lin(image).view(4, 30, 7, 7).detach().cpu(), gx, gc, om)
+    assert abs(loss.item() - ref.item()) <= RTOL * abs(ref.item())
+
+
+def test_empty_batch(dev):
+    head = YOLOv1Head()
+    z = torch.zeros(0, 30, 7, 7, device=dev)
+    terms, grad = head.loss_fwd_bwd(z, torch.zeros(0, 49, 1, 4, device=dev),
+                                    torch.zeros(0, 49, 1, 20, device=dev),
+                                    torch.zeros(0, 49, 1, 1, dtype=torch.bool, device=dev))
+    assert terms.cpu().tolist() == [0.0] * 5 and grad.numel() == 0

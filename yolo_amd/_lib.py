@@ -1,0 +1,89 @@
+"""ctypes binding of libyolohead.so (the C ABI of include/yolo_head.h).
+
+The library is built in-tree by ``yolo_amd/csrc/Makefile`` (or
+``__graft_entry__.build()``) into ``yolo_amd/lib/``.  There is no fallback: if
+the shared object is missing, loading raises and every op of the package fails.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+import torch  # noqa: F401  -- must be imported first: its HIP runtime is the one the library binds to
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libyolohead.so")
+
+# error codes of include/yolo_head.h
+YH_OK = 0
+YH_ERR_NULL = -1
+YH_ERR_SHAPE = -2
+YH_ERR_WORKSPACE = -3
+YH_ERR_ALIGN = -4
+YH_ERR_ARG = -5
+YH_ERR_UNSUPPORTED = -6
+
+YH_OP_LOSS = 0
+YH_OP_DECODE_NMS = 1
+YH_OP_DECODE_GRID = 2
+YH_OP_NMS = 3
+
+YH_MODE_REFERENCE = 0
+YH_MODE_DENSE = 1
+
+YH_MAX_CANDIDATES = 1024
+
+# name -> (restype, argtypes); mirrors include/yolo_head.h declaration by declaration
+SIGNATURES = {
+    "yh_version": (c_int, []),
+    "yh_strerror": (c_char_p, [c_int]),
+    "yh_workspace_bytes": (c_size_t, [c_int, c_int64, c_int, c_int, c_int]),
+    "yh_loss_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_int,
+                                c_float, c_float, c_float, c_void_p]),
+    "yh_scale_grad": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "yh_decode_grid": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_float, c_int64, c_int, c_int, c_int, c_int,
+                               c_void_p]),
+    "yh_decode_candidates": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "yh_decode_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
+                              c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "yh_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                       c_float, c_float, c_int64, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+class YoloHeadError(RuntimeError):
+    def __init__(self, rc: int, msg: str):
+        super().__init__(f"{msg} (rc={rc})")
+        self.rc = rc
+
+
+def load() -> ctypes.CDLL:
+    """Load the library once; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `make -C yolo_amd/csrc` "
+                "(hipcc --offload-arch=gfx950); yolo_amd has no CPU or PyTorch fallback"
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def strerror(rc: int) -> str:
+    return load().yh_strerror(rc).decode()
+
+
+def check(rc: int) -> None:
+    if rc != YH_OK:
+        raise YoloHeadError(rc, strerror(rc))

@@ -1,0 +1,127 @@
+// Scalar device math of the YOLOv1 head: sigmoid, grid decode, IoU forward and
+// backward.  Every function restates one reference primitive in fp32 with the
+// reference's operation order; the translation unit is compiled with
+// -ffp-contract=off so no multiply-add is fused and the IoU bits match a CPU
+// evaluation of the same expression.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace yh {
+
+struct Box {
+    float l, t, r, b;
+};
+
+// torch.sigmoid
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// denormalize_xywh (model.py:167-183) then xywh_to_ltrb (model.py:150-155) for one
+// box of the cell whose grid offsets are (xoff, yoff) = cell_size * (i, j).
+// ul/ut/ur/ub receive the edges before the one-sided clips (the backward needs
+// to know whether a clip was active).
+__device__ __forceinline__ Box decode_box(float nx, float ny, float nw, float nh, float xoff,
+                                          float yoff, float cellf, float imgf, float& ul,
+                                          float& ut, float& ur, float& ub) {
+    const float x = nx * cellf + xoff;
+    const float y = ny * cellf + yoff;
+    const float hw = (nw * imgf) / 2.0f;
+    const float hh = (nh * imgf) / 2.0f;
+    ul = x - hw;
+    ut = y - hh;
+    ur = x + hw;
+    ub = y + hh;
+    Box o;
+    o.l = fmaxf(ul, 0.0f);
+    o.t = fmaxf(ut, 0.0f);
+    o.r = fminf(ur, imgf);
+    o.b = fminf(ub, imgf);
+    return o;
+}
+
+__device__ __forceinline__ Box decode_box(float nx, float ny, float nw, float nh, float xoff,
+                                          float yoff, float cellf, float imgf) {
+    float a, b, c, d;
+    return decode_box(nx, ny, nw, nh, xoff, yoff, cellf, imgf, a, b, c, d);
+}
+
+// get_area (eval.py:22-32)
+__device__ __forceinline__ float box_area(const Box& p) {
+    return fmaxf(p.r - p.l, 0.0f) * fmaxf(p.b - p.t, 0.0f);
+}
+
+// get_iou (eval.py:53-65) for one pair: inter / ((a1 + a2) - inter), 0/0 -> 0.
+__device__ __forceinline__ float iou_pair(const Box& p, const Box& g) {
+    const float a1 = box_area(p);
+    const float a2 = box_area(g);
+    const float iw = fmaxf(fminf(p.r, g.r) - fmaxf(p.l, g.l), 0.0f);
+    const float ih = fmaxf(fminf(p.b, g.b) - fmaxf(p.t, g.t), 0.0f);
+    const float inter = iw * ih;
+    const float uni = (a1 + a2) - inter;
+    return uni == 0.0f ? 0.0f : inter / uni;
+}
+
+// share of the gradient that max(a, b) (or min) sends to a: all of it when a
+// wins, half on an exact tie (torch.maximum / torch.minimum backward).
+__device__ __forceinline__ float pick_max(float a, float b) {
+    return a > b ? 1.0f : (a == b ? 0.5f : 0.0f);
+}
+__device__ __forceinline__ float pick_min(float a, float b) {
+    return a < b ? 1.0f : (a == b ? 0.5f : 0.0f);
+}
+
+// d iou_pair(p, g) / d p, scaled by the upstream gradient `giou` (g is constant).
+// torch.clip(x, min=0) passes the gradient where x >= 0.
+__device__ __forceinline__ void iou_pair_bwd(const Box& p, const Box& g, float giou, float& gl,
+                                             float& gt, float& gr, float& gb) {
+    const float w1 = p.r - p.l, h1 = p.b - p.t;
+    const float cw1 = fmaxf(w1, 0.0f), ch1 = fmaxf(h1, 0.0f);
+    const float a1 = cw1 * ch1;
+    const float a2 = box_area(g);
+    const float il = fmaxf(p.l, g.l), it = fmaxf(p.t, g.t);
+    const float ir = fminf(p.r, g.r), ib = fminf(p.b, g.b);
+    const float iw = ir - il, ih = ib - it;
+    const float ciw = fmaxf(iw, 0.0f), cih = fmaxf(ih, 0.0f);
+    const float inter = ciw * cih;
+    const float uni = (a1 + a2) - inter;
+    gl = gt = gr = gb = 0.0f;
+    if (uni == 0.0f) return;  // torch.where routes no gradient into the quotient
+    // iou = inter / uni, uni = a1 + a2 - inter
+    const float g_uni = -giou * inter / (uni * uni);
+    const float g_inter = giou / uni - g_uni;
+    const float g_a1 = g_uni;
+    // intersection extent
+    const float g_iw = iw >= 0.0f ? g_inter * cih : 0.0f;
+    const float g_ih = ih >= 0.0f ? g_inter * ciw : 0.0f;
+    gr += g_iw * pick_min(p.r, g.r);
+    gl -= g_iw * pick_max(p.l, g.l);
+    gb += g_ih * pick_min(p.b, g.b);
+    gt -= g_ih * pick_max(p.t, g.t);
+    // own area
+    const float g_w1 = w1 >= 0.0f ? g_a1 * ch1 : 0.0f;
+    const float g_h1 = h1 >= 0.0f ? g_a1 * cw1 : 0.0f;
+    gr += g_w1;
+    gl -= g_w1;
+    gb += g_h1;
+    gt -= g_h1;
+}
+
+// monotone map of a float to an unsigned key (larger float -> larger key)
+__device__ __forceinline__ uint32_t float_to_ordered(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// ---- wave64 helpers -----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace yh

@@ -1,0 +1,263 @@
+// Fused YOLOv1 loss forward + backward (model.py:190-317 and its autograd
+// backward).  One lane owns one grid cell of one image: it reads the cell's D
+// logits (stride S*S apart in the channel-major head tensor, so consecutive
+// lanes read consecutive addresses), the cell's ground truth, evaluates the
+// three loss terms and writes the cell's D gradients.  Loss partials are
+// reduced wave -> workgroup -> one row of `partials` per workgroup; a second
+// tiny kernel adds the rows in a fixed order, so results are reproducible bit
+// for bit.
+#pragma once
+#include "head_math.hpp"
+
+namespace yh {
+
+constexpr int LOSS_THREADS = 256;
+
+// BX_CT / C_CT > 0: predictor and class counts fixed at compile time (loops
+// unroll, repeated loads and exponentials are shared); 0: taken from nb_rt /
+// nc_rt at run time.
+template <int BX_CT, int C_CT>
+__device__ __forceinline__ void loss_cell(const float* __restrict__ p, float* __restrict__ g,
+                                          const float* __restrict__ gxywh,
+                                          const float* __restrict__ gcls, bool obj, int cell,
+                                          int S, int S2, int nb_rt, int nc_rt, float cellf,
+                                          float imgf, float lc, float ln, float inv_gb,
+                                          float& acc_coord, float& acc_conf, float& acc_cls) {
+    const int nb = BX_CT > 0 ? BX_CT : nb_rt;
+    const int nc = C_CT > 0 ? C_CT : nc_rt;
+    constexpr bool kStatic = BX_CT > 0 && C_CT > 0;
+    constexpr int kD = kStatic ? 5 * BX_CT + C_CT : 1;
+
+    // Compile-time shape: all D logits of the cell are fetched up front, with no
+    // dependence on obj_mask, so the whole cell costs one memory round trip; the
+    // lines are needed by neighbouring cells anyway.  Run-time shape: read on use.
+    float v[kD];
+    if constexpr (kStatic) {
+#pragma unroll
+        for (int ch = 0; ch < kD; ++ch) v[ch] = p[ch * S2];
+    }
+    auto logit = [&](int ch) -> float {
+        if constexpr (kStatic) return v[ch];
+        else return p[ch * S2];
+    };
+
+    int best = 0;
+    float bnx = 0.f, bny = 0.f, bnw = 0.f, bnh = 0.f, biou = 0.f;
+    float gnx = 0.f, gny = 0.f, gnw = 0.f, gnh = 0.f;
+    float xoff = 0.f, yoff = 0.f;
+    Box gbox = {0.f, 0.f, 0.f, 0.f};
+    if (obj) {
+        // ground truth through the same decode as the predictions (model.py:261-262)
+        const float4 gv = *reinterpret_cast<const float4*>(gxywh);
+        gnx = gv.x; gny = gv.y; gnw = gv.z; gnh = gv.w;
+        xoff = cellf * (float)(cell / S);   // first spatial axis carries x (model.py:175-177)
+        yoff = cellf * (float)(cell % S);
+        gbox = decode_box(gnx, gny, gnw, gnh, xoff, yoff, cellf, imgf);
+        // responsible predictor: highest IoU, first index on ties (model.py:210)
+#pragma unroll
+        for (int k = 0; k < nb; ++k) {
+            const float nx = sigmoidf_(logit(5 * k + 0));
+            const float ny = sigmoidf_(logit(5 * k + 1));
+            const float nw = sigmoidf_(logit(5 * k + 2));
+            const float nh = sigmoidf_(logit(5 * k + 3));
+            const float iou = iou_pair(decode_box(nx, ny, nw, nh, xoff, yoff, cellf, imgf), gbox);
+            if (k == 0 || iou > biou) {
+                best = k; biou = iou; bnx = nx; bny = ny; bnw = nw; bnh = nh;
+            }
+        }
+    }
+
+#pragma unroll
+    for (int k = 0; k < nb; ++k) {
+        const float conf = sigmoidf_(logit(5 * k + 4));
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, gc;
+        if (obj && k == best) {
+            // coordinate term (model.py:224-240)
+            const float dx = bnx - gnx, dy = bny - gny;
+            const float sw = sqrtf(bnw), sh = sqrtf(bnh);
+            const float dw = sw - sqrtf(gnw), dh = sh - sqrtf(gnh);
+            acc_coord += lc * ((dx * dx + dy * dy) + (dw * dw + dh * dh));
+            // objectness term (model.py:267-269); IoU is part of the graph
+            const float dc = conf - biou;
+            acc_conf += dc * dc;
+            float ul, ut, ur, ub, gl, gt, gr, gb;
+            const Box pb = decode_box(bnx, bny, bnw, bnh, xoff, yoff, cellf, imgf, ul, ut, ur, ub);
+            iou_pair_bwd(pb, gbox, -2.0f * dc, gl, gt, gr, gb);
+            // xywh_to_ltrb backward: a clipped edge passes nothing
+            gl = ul >= 0.0f ? gl : 0.0f;
+            gt = ut >= 0.0f ? gt : 0.0f;
+            gr = ur <= imgf ? gr : 0.0f;
+            gb = ub <= imgf ? gb : 0.0f;
+            const float gx_iou = (gl + gr) * cellf;
+            const float gy_iou = (gt + gb) * cellf;
+            const float gw_iou = (gr - gl) * 0.5f * imgf;
+            const float gh_iou = (gb - gt) * 0.5f * imgf;
+            // d/dn of lc*(sqrt(n) - sqrt(g))^2 times sigmoid' = lc*(sw - sg)*sw*(1 - n)
+            g0 = (2.0f * lc * dx + gx_iou) * (bnx * (1.0f - bnx));
+            g1 = (2.0f * lc * dy + gy_iou) * (bny * (1.0f - bny));
+            g2 = lc * dw * sw * (1.0f - bnw) + gw_iou * (bnw * (1.0f - bnw));
+            g3 = lc * dh * sh * (1.0f - bnh) + gh_iou * (bnh * (1.0f - bnh));
+            gc = 2.0f * dc * (conf * (1.0f - conf));
+        } else {
+            // no-object term (model.py:270-274)
+            acc_conf += ln * (conf * conf);
+            gc = 2.0f * ln * conf * (conf * (1.0f - conf));
+        }
+        g[(5 * k + 0) * S2] = g0 * inv_gb;
+        g[(5 * k + 1) * S2] = g1 * inv_gb;
+        g[(5 * k + 2) * S2] = g2 * inv_gb;
+        g[(5 * k + 3) * S2] = g3 * inv_gb;
+        g[(5 * k + 4) * S2] = gc * inv_gb;
+    }
+
+    // class term (model.py:278-294): squared error on the softmax
+    const int c0 = 5 * nb;
+    float* gcl = g + 5 * nb * S2;
+    if (obj) {
+        float m = logit(c0);
+#pragma unroll
+        for (int j = 1; j < nc; ++j) m = fmaxf(m, logit(c0 + j));
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < nc; ++j) s += expf(logit(c0 + j) - m);
+        float dot = 0.f, l2 = 0.f;
+        if constexpr (C_CT > 0 && C_CT % 4 == 0) {
+            float gtc[C_CT];
+#pragma unroll
+            for (int j = 0; j < C_CT / 4; ++j) {
+                const float4 v = reinterpret_cast<const float4*>(gcls)[j];
+                gtc[4 * j] = v.x; gtc[4 * j + 1] = v.y; gtc[4 * j + 2] = v.z; gtc[4 * j + 3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < C_CT; ++j) {
+                const float pj = expf(logit(c0 + j) - m) / s;
+                const float d = pj - gtc[j];
+                l2 += d * d;
+                dot += 2.0f * d * pj;
+            }
+#pragma unroll
+            for (int j = 0; j < C_CT; ++j) {
+                const float pj = expf(logit(c0 + j) - m) / s;
+                gcl[j * S2] = pj * (2.0f * (pj - gtc[j]) - dot) * inv_gb;
+            }
+        } else {
+            for (int j = 0; j < nc; ++j) {
+                const float pj = expf(logit(c0 + j) - m) / s;
+                const float d = pj - gcls[j];
+                l2 += d * d;
+                dot += 2.0f * d * pj;
+            }
+            for (int j = 0; j < nc; ++j) {
+                const float pj = expf(logit(c0 + j) - m) / s;
+                gcl[j * S2] = pj * (2.0f * (pj - gcls[j]) - dot) * inv_gb;
+            }
+        }
+        acc_cls += l2;
+    } else {
+#pragma unroll
+        for (int j = 0; j < nc; ++j) gcl[j * S2] = 0.0f;
+    }
+}
+
+template <int BX_CT, int C_CT>
+__global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_kernel(
+    const float* __restrict__ pred, const float* __restrict__ gt_xywh,
+    const float* __restrict__ gt_cls, const uint8_t* __restrict__ obj_mask,
+    float* __restrict__ grad, float* __restrict__ partials, long long batch, int S, int nb_rt,
+    int nc_rt, int imgs_per_block, float cellf, float imgf, float lc, float ln, float inv_gb) {
+    const int nb = BX_CT > 0 ? BX_CT : nb_rt;
+    const int nc = C_CT > 0 ? C_CT : nc_rt;
+    const int S2 = S * S;
+    const long long D = 5 * nb + nc;
+    const long long img0 = (long long)blockIdx.x * imgs_per_block;
+    const int nitems = imgs_per_block * S2;
+
+    float acc_coord = 0.f, acc_conf = 0.f, acc_cls = 0.f;
+    for (int item = threadIdx.x; item < nitems; item += LOSS_THREADS) {
+        const int gi = item / S2;
+        const int cell = item - gi * S2;
+        const long long img = img0 + gi;
+        if (img < batch) {
+            const long long tcell = img * S2 + cell;
+            const long long off = img * D * S2 + cell;
+            loss_cell<BX_CT, C_CT>(pred + off, grad + off, gt_xywh + tcell * 4,
+                                   gt_cls + tcell * nc, obj_mask[tcell] != 0, cell, S, S2, nb,
+                                   nc, cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf,
+                                   acc_cls);
+        }
+    }
+
+    // wave -> workgroup reduction in a fixed order
+    __shared__ float red[LOSS_THREADS / 64][3];
+    acc_coord = wave_sum(acc_coord);
+    acc_conf = wave_sum(acc_conf);
+    acc_cls = wave_sum(acc_cls);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[wave][0] = acc_coord;
+        red[wave][1] = acc_conf;
+        red[wave][2] = acc_cls;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < LOSS_THREADS / 64; ++w) s += red[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * 4 + threadIdx.x] = s;
+    }
+}
+
+// Adds the per-workgroup rows in a fixed order (fp64 accumulation) and writes
+// coord, conf, class, total and total * inv_gb.
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ partials,
+                                                            int nrows, float inv_gb,
+                                                            float* __restrict__ loss_terms) {
+    __shared__ double red[256][3];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int r = threadIdx.x; r < nrows; r += 256) {
+        a0 += (double)partials[(size_t)r * 4 + 0];
+        a1 += (double)partials[(size_t)r * 4 + 1];
+        a2 += (double)partials[(size_t)r * 4 + 2];
+    }
+    red[threadIdx.x][0] = a0;
+    red[threadIdx.x][1] = a1;
+    red[threadIdx.x][2] = a2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            red[threadIdx.x][0] += red[threadIdx.x + s][0];
+            red[threadIdx.x][1] += red[threadIdx.x + s][1];
+            red[threadIdx.x][2] += red[threadIdx.x + s][2];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double c = red[0][0], f = red[0][1], k = red[0][2];
+        const double tot = (c + f) + k;
+        loss_terms[0] = (float)c;
+        loss_terms[1] = (float)f;
+        loss_terms[2] = (float)k;
+        loss_terms[3] = (float)tot;
+        loss_terms[4] = (float)(tot * (double)inv_gb);
+    }
+}
+
+// grad[i] *= *scale, skipped entirely when *scale == 1 (the loss.backward() case).
+__global__ __launch_bounds__(256) void scale_grad_kernel(float* __restrict__ grad,
+                                                         const float* __restrict__ scale,
+                                                         long long n) {
+    const float s = *scale;
+    if (s == 1.0f) return;
+    const long long n4 = n / 4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    float4* g4 = reinterpret_cast<float4*>(grad);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = g4[i];
+        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+        g4[i] = v;
+    }
+    for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        grad[i] *= s;
+}
+
+}  // namespace yh

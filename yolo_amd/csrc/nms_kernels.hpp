@@ -1,0 +1,336 @@
+// Decode + confidence threshold + per-class greedy NMS, one image per group of
+// NT threads (NT = 64: one wavefront per image, four images per workgroup, no
+// workgroup barriers; NT = 256: one workgroup per image).
+//
+// Phases per image, all on chip:
+//   A  candidates into registers (decoded from the head tensor, or loaded)
+//   B  64-bit sort key (class | inverted score | slot) per candidate; every
+//      candidate counts the keys below its own (its rank) and the keys of a
+//      lower class (the start of its class segment) from broadcast LDS reads
+//   C  scatter to rank order in LDS: classes become contiguous segments, each
+//      in descending score order
+//   D  greedy suppression, all classes at once: in step s every candidate looks
+//      at the s-th member of its own segment (the pivot); if the pivot is still
+//      alive and IoU > threshold the candidate dies.  Liveness is a bitmask in
+//      LDS rebuilt with one ballot per wavefront per step, so a pivot's bit is
+//      final before it is used.  The step count is the longest segment - 1.
+//   E  kept rows get their output slot from a prefix popcount over the
+//      liveness words, are staged in LDS and leave with coalesced stores.
+#pragma once
+#include "head_math.hpp"
+
+namespace yh {
+
+constexpr int NMS_BLOCK = 256;
+
+struct NmsArgs {
+    // source 0: the head tensor
+    const float* pred;
+    // source 1: caller-supplied candidates
+    const float* c_ltrb;
+    const float* c_score;
+    const int32_t* c_cls;
+    const uint8_t* c_present;
+    // outputs
+    float* dets;
+    int32_t* keep_count;
+    int32_t* keep_idx;
+    long long batch;
+    int S, nb, nc, mode;
+    int nslot;  // candidate slots per image (S*S in reference mode, S*S*nb dense, N for source 1)
+    int nout;   // rows of dets per image
+    float cellf, imgf, conf_thr, iou_thr;
+    // per-image LDS region: byte offsets of the arrays inside it, and its size
+    int off_keys, off_box, off_meta, off_alive, off_misc, off_stage, off_kidx, off_ccls;
+    int region_bytes;
+};
+
+// ---- decode primitives shared by every kernel that forms candidates --------------
+// class of a cell: argmax of the class logits, first index on ties
+__device__ __forceinline__ int cell_class(const float* __restrict__ p, int c0, int nc, int S2) {
+    int best = 0;
+    float m = p[c0 * S2];
+    for (int j = 1; j < nc; ++j) {
+        const float v = p[(c0 + j) * S2];
+        if (v > m) { m = v; best = j; }
+    }
+    return best;
+}
+
+// predictor with the higher confidence, first index on ties (torch.max, model.py:387)
+__device__ __forceinline__ int cell_best_conf(const float* __restrict__ p, int nb, int S2,
+                                              float& conf_best) {
+    int best = 0;
+    conf_best = sigmoidf_(p[4 * S2]);
+    for (int k = 1; k < nb; ++k) {
+        const float c = sigmoidf_(p[(5 * k + 4) * S2]);
+        if (c > conf_best) { conf_best = c; best = k; }
+    }
+    return best;
+}
+
+// box of predictor k of a cell in pixels (model.py:185-188)
+__device__ __forceinline__ Box cell_box(const float* __restrict__ p, int k, int cell, int S,
+                                        int S2, float cellf, float imgf) {
+    const float nx = sigmoidf_(p[(5 * k + 0) * S2]);
+    const float ny = sigmoidf_(p[(5 * k + 1) * S2]);
+    const float nw = sigmoidf_(p[(5 * k + 2) * S2]);
+    const float nh = sigmoidf_(p[(5 * k + 3) * S2]);
+    return decode_box(nx, ny, nw, nh, cellf * (float)(cell / S), cellf * (float)(cell % S),
+                      cellf, imgf);
+}
+
+template <int NT>
+__device__ __forceinline__ void group_sync() {
+    if constexpr (NT == 64) {
+        // one wavefront: LDS operations of a wave complete in order, only the
+        // compiler must not reorder across this point
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
+template <int NT, int ITEMS, int SRC>
+__global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int IPB = NMS_BLOCK / NT;  // images per workgroup
+    constexpr int NW = NT / 64;          // wavefronts per image
+    const int sub = threadIdx.x / NT;
+    const int t = threadIdx.x % NT;
+    const int lane = threadIdx.x & 63;
+    const int wv = t >> 6;  // wavefront within the image group
+    const long long img = (long long)blockIdx.x * IPB + sub;
+    const bool live_img = img < a.batch;
+    // NT == 64: a whole wavefront leaves and no workgroup barrier is used below;
+    // NT == 256: the grid has exactly one workgroup per image, so this never fires.
+    if (!live_img) return;
+
+    unsigned char* region = smem + (size_t)sub * a.region_bytes;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(region + a.off_keys);
+    float4* sbox = reinterpret_cast<float4*>(region + a.off_box);
+    int4* smeta = reinterpret_cast<int4*>(region + a.off_meta);
+    unsigned long long* alive = reinterpret_cast<unsigned long long*>(region + a.off_alive);
+    int* misc = reinterpret_cast<int*>(region + a.off_misc);  // [0] valid count, [1] max pos
+    float* stage = reinterpret_cast<float*>(region + a.off_stage);
+    int* kidx = reinterpret_cast<int*>(region + a.off_kidx);
+    int* ccls = reinterpret_cast<int*>(region + a.off_ccls);
+
+    const int nslot = a.nslot;
+    const int S2 = a.S * a.S;
+
+    // ---- phase A: candidates ---------------------------------------------------
+    Box cbox[ITEMS];
+    float cscore[ITEMS];
+    int ccl[ITEMS], cidx[ITEMS];
+    bool cvalid[ITEMS];
+#pragma unroll
+    for (int e = 0; e < ITEMS; ++e) {
+        cbox[e] = {0.f, 0.f, 0.f, 0.f};
+        cscore[e] = 0.f; ccl[e] = 0; cidx[e] = 0; cvalid[e] = false;
+    }
+    if (t == 0) { misc[0] = 0; misc[1] = 0; }
+
+    if constexpr (SRC == 0) {
+        const long long D = 5 * a.nb + a.nc;
+        const float* pimg = a.pred + (live_img ? img : 0) * D * S2;
+        if (a.mode == 0) {
+            // slot = cell; the higher-confidence predictor is the candidate
+#pragma unroll
+            for (int e = 0; e < ITEMS; ++e) {
+                const int cell = e * NT + t;
+                if (cell < nslot && live_img) {
+                    const float* p = pimg + cell;
+                    float cb;
+                    const int k = cell_best_conf(p, a.nb, S2, cb);
+                    cbox[e] = cell_box(p, k, cell, a.S, S2, a.cellf, a.imgf);
+                    cscore[e] = cb;
+                    ccl[e] = cell_class(p, 5 * a.nb, a.nc, S2);
+                    cidx[e] = cell * a.nb + k;
+                    cvalid[e] = cb >= a.conf_thr;
+                }
+            }
+        } else {
+            // slot = cell*nb + k; the class is computed once per cell
+            for (int cell = t; cell < S2; cell += NT)
+                ccls[cell] = live_img ? cell_class(pimg + cell, 5 * a.nb, a.nc, S2) : 0;
+            group_sync<NT>();
+#pragma unroll
+            for (int e = 0; e < ITEMS; ++e) {
+                const int n = e * NT + t;
+                if (n < nslot && live_img) {
+                    const int cell = n / a.nb;
+                    const int k = n - cell * a.nb;
+                    const float* p = pimg + cell;
+                    cbox[e] = cell_box(p, k, cell, a.S, S2, a.cellf, a.imgf);
+                    cscore[e] = sigmoidf_(p[(5 * k + 4) * S2]);
+                    ccl[e] = ccls[cell];
+                    cidx[e] = n;
+                    cvalid[e] = cscore[e] >= a.conf_thr;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            const int n = e * NT + t;
+            if (n < nslot && live_img) {
+                const long long gi = img * nslot + n;
+                const float4 bx = reinterpret_cast<const float4*>(a.c_ltrb)[gi];
+                cbox[e] = {bx.x, bx.y, bx.z, bx.w};
+                cscore[e] = a.c_score[gi];
+                ccl[e] = a.c_cls[gi];
+                cidx[e] = n;
+                const bool present = a.c_present ? a.c_present[gi] != 0 : true;
+                cvalid[e] = present && cscore[e] >= a.conf_thr && ccl[e] >= 0 && ccl[e] <= 32767;
+            }
+        }
+    }
+
+    // ---- phase B: keys, rank, segment start ---------------------------------------
+    unsigned long long key[ITEMS], clsbase[ITEMS];
+#pragma unroll
+    for (int e = 0; e < ITEMS; ++e) {
+        const int n = e * NT + t;
+        const unsigned int sk = ~float_to_ordered(cscore[e] + 0.0f);  // descending score
+        clsbase[e] = (unsigned long long)(unsigned int)ccl[e] << 48;
+        key[e] = cvalid[e] ? (clsbase[e] | ((unsigned long long)sk << 16) | (unsigned int)n)
+                           : ~0ull;
+        keys[n] = key[e];
+    }
+    group_sync<NT>();
+    int rank[ITEMS], seg[ITEMS];
+#pragma unroll
+    for (int e = 0; e < ITEMS; ++e) { rank[e] = 0; seg[e] = 0; }
+    for (int j = 0; j < nslot; ++j) {
+        const unsigned long long kj = keys[j];  // same address in every lane: broadcast
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            rank[e] += kj < key[e] ? 1 : 0;
+            seg[e] += kj < clsbase[e] ? 1 : 0;
+        }
+    }
+
+    // ---- phase C: scatter to rank order ---------------------------------------------
+    int nv_local = 0, mp_local = 0;
+#pragma unroll
+    for (int e = 0; e < ITEMS; ++e) {
+        if (cvalid[e]) {
+            sbox[rank[e]] = make_float4(cbox[e].l, cbox[e].t, cbox[e].r, cbox[e].b);
+            smeta[rank[e]] = make_int4(__float_as_int(cscore[e]), ccl[e], cidx[e], seg[e]);
+            mp_local = max(mp_local, rank[e] - seg[e]);
+        }
+        nv_local += __popcll(__ballot(cvalid[e]));
+    }
+    mp_local = wave_max(mp_local);
+    if (lane == 0) {
+        atomicAdd(&misc[0], nv_local);
+        atomicMax(&misc[1], mp_local);
+    }
+    group_sync<NT>();
+    const int nvalid = misc[0];
+    const int maxpos = misc[1];
+
+    // ---- phase D: greedy suppression over sorted positions ----------------------------
+    Box mybox[ITEMS];
+    int4 mymeta[ITEMS];
+    bool al[ITEMS];
+#pragma unroll
+    for (int e = 0; e < ITEMS; ++e) {
+        const int i = e * NT + t;
+        al[e] = i < nvalid;
+        mybox[e] = {0.f, 0.f, 0.f, 0.f};
+        mymeta[e] = make_int4(0, 0, 0, 0);
+        if (al[e]) {
+            const float4 b = sbox[i];
+            mybox[e] = {b.x, b.y, b.z, b.w};
+            mymeta[e] = smeta[i];
+        }
+        const unsigned long long w = __ballot(al[e]);
+        if (lane == 0) alive[e * NW + wv] = w;
+    }
+    group_sync<NT>();
+    for (int step = 0; step < maxpos; ++step) {
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            const int i = e * NT + t;
+            if (al[e] && i - mymeta[e].w > step) {
+                const int pv = mymeta[e].w + step;  // pivot: step-th member of my class segment
+                if ((alive[pv >> 6] >> (pv & 63)) & 1ull) {
+                    const float4 b = sbox[pv];
+                    const Box pb = {b.x, b.y, b.z, b.w};
+                    if (iou_pair(pb, mybox[e]) > a.iou_thr) al[e] = false;
+                }
+            }
+        }
+        group_sync<NT>();  // every read of the liveness words precedes their update
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            const unsigned long long w = __ballot(al[e]);
+            if (lane == 0) alive[e * NW + wv] = w;
+        }
+        group_sync<NT>();
+    }
+
+    // ---- phase E: compact the survivors, stage, store -----------------------------------
+    const int nout = a.nout;
+    for (int i = t; i < nout * 6; i += NT) stage[i] = 0.0f;
+    for (int i = t; i < nout; i += NT) kidx[i] = -1;
+    group_sync<NT>();
+    int total = 0;
+#pragma unroll
+    for (int w = 0; w < ITEMS * NW; ++w) total += __popcll(alive[w]);
+#pragma unroll
+    for (int e = 0; e < ITEMS; ++e) {
+        if (al[e]) {
+            const int myw = e * NW + wv;
+            int pos = __popcll(alive[myw] & ((1ull << lane) - 1ull));
+            for (int w = 0; w < myw; ++w) pos += __popcll(alive[w]);
+            float* row = stage + pos * 6;
+            row[0] = mybox[e].l; row[1] = mybox[e].t; row[2] = mybox[e].r; row[3] = mybox[e].b;
+            row[4] = __int_as_float(mymeta[e].x);
+            row[5] = (float)mymeta[e].y;
+            kidx[pos] = mymeta[e].z;
+        }
+    }
+    group_sync<NT>();
+    if (live_img) {
+        float* dst = a.dets + img * (long long)nout * 6;
+        for (int i = t; i < nout * 6; i += NT) dst[i] = stage[i];
+        if (a.keep_idx) {
+            int32_t* kd = a.keep_idx + img * (long long)nout;
+            for (int i = t; i < nout; i += NT) kd[i] = kidx[i];
+        }
+        if (t == 0) a.keep_count[img] = total;
+    }
+}
+
+// ---- candidates to global memory (the values nms_kernel<.,.,0> forms in registers) ---
+__global__ __launch_bounds__(256) void decode_candidates_kernel(
+    const float* __restrict__ pred, float* __restrict__ c_ltrb, float* __restrict__ c_score,
+    int32_t* __restrict__ c_cls, uint8_t* __restrict__ c_present, long long batch, int S,
+    int nb, int nc, int mode, float cellf, float imgf) {
+    const int S2 = S * S;
+    const long long total = batch * S2;
+    const long long D = 5 * nb + nc;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+         g += (long long)gridDim.x * blockDim.x) {
+        const long long img = g / S2;
+        const int cell = (int)(g - img * S2);
+        const float* p = pred + img * D * S2 + cell;
+        const int cls = cell_class(p, 5 * nb, nc, S2);
+        float cb;
+        const int best = cell_best_conf(p, nb, S2, cb);
+        for (int k = 0; k < nb; ++k) {
+            const long long o = g * nb + k;
+            const Box b = cell_box(p, k, cell, S, S2, cellf, imgf);
+            reinterpret_cast<float4*>(c_ltrb)[o] = make_float4(b.l, b.t, b.r, b.b);
+            c_score[o] = sigmoidf_(p[(5 * k + 4) * S2]);
+            c_cls[o] = cls;
+            c_present[o] = (mode == 1 || k == best) ? 1 : 0;
+        }
+    }
+}
+
+}  // namespace yh

@@ -1,0 +1,266 @@
+// libyolohead: the C ABI declared in include/yolo_head.h.  Host side only checks
+// arguments and enqueues kernels on the caller's stream; it never allocates,
+// synchronises or keeps state, so every entry point can be captured into a
+// HIP graph.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/yolo_head.h"
+#include "decode_kernels.hpp"
+#include "loss_kernels.hpp"
+#include "nms_kernels.hpp"
+
+namespace {
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+int check_shape(int64_t batch, int S, int Bx, int C, int img_size) {
+    if (batch < 0 || S < 1 || S > YH_MAX_S || Bx < 1 || Bx > YH_MAX_BX || C < 1 ||
+        C > YH_MAX_C || img_size < 1)
+        return YH_ERR_SHAPE;
+    // cell_size = img_size // S (model.py:114) must tile the image exactly, as the
+    // reference's arange(0, img_size, cell_size) grid requires (model.py:172-174)
+    if (img_size % S != 0) return YH_ERR_SHAPE;
+    if (batch * (int64_t)S * S > (int64_t)1 << 40) return YH_ERR_SHAPE;
+    return YH_OK;
+}
+
+inline int loss_imgs_per_block(int S) {
+    const int S2 = S * S;
+    return S2 <= yh::LOSS_THREADS ? yh::LOSS_THREADS / S2 : 1;
+}
+
+inline int64_t loss_blocks(int64_t batch, int S) {
+    const int g = loss_imgs_per_block(S);
+    return (batch + g - 1) / g;
+}
+
+inline int launch_status() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? YH_OK : (int)e;
+}
+
+inline int round16(int x) { return (x + 15) & ~15; }
+
+// LDS layout of one image's region in nms_kernel
+void nms_layout(yh::NmsArgs& a, int slot_pad) {
+    const int sort_bytes = slot_pad * (8 + 16 + 16);
+    const int out_bytes = round16(a.nout * 24) + round16(a.nout * 4);
+    a.off_keys = 0;
+    a.off_box = slot_pad * 8;
+    a.off_meta = slot_pad * 24;
+    // the output staging reuses the sort arrays: they are dead once suppression ends
+    a.off_stage = 0;
+    a.off_kidx = round16(a.nout * 24);
+    int off = sort_bytes > out_bytes ? sort_bytes : out_bytes;
+    a.off_alive = off;
+    off += round16((slot_pad / 64) * 8);
+    a.off_misc = off;
+    off += 16;
+    a.off_ccls = off;
+    off += round16(a.S * a.S * 4);
+    a.region_bytes = off;
+}
+
+template <int SRC>
+int launch_nms(yh::NmsArgs a, hipStream_t st) {
+    if (a.batch == 0) return YH_OK;
+    if (a.nslot > YH_MAX_CANDIDATES || a.nout > YH_MAX_CANDIDATES) return YH_ERR_UNSUPPORTED;
+#define YH_NMS_CASE(NT, ITEMS)                                                            \
+    {                                                                                     \
+        nms_layout(a, NT * ITEMS);                                                        \
+        const int ipb = yh::NMS_BLOCK / NT;                                               \
+        const unsigned grid = (unsigned)((a.batch + ipb - 1) / ipb);                      \
+        const size_t lds = (size_t)a.region_bytes * ipb;                                  \
+        hipLaunchKernelGGL((yh::nms_kernel<NT, ITEMS, SRC>), dim3(grid), dim3(yh::NMS_BLOCK), \
+                           lds, st, a);                                                   \
+        return launch_status();                                                           \
+    }
+    if (a.nslot <= 64) YH_NMS_CASE(64, 1)
+    if (a.nslot <= 128) YH_NMS_CASE(64, 2)
+    if (a.nslot <= 256) YH_NMS_CASE(256, 1)
+    if (a.nslot <= 512) YH_NMS_CASE(256, 2)
+    YH_NMS_CASE(256, 4)
+#undef YH_NMS_CASE
+}
+
+}  // namespace
+
+extern "C" {
+
+int yh_version(void) { return YH_VERSION; }
+
+const char* yh_strerror(int rc) {
+    switch (rc) {
+        case YH_OK: return "ok";
+        case YH_ERR_NULL: return "yolo_head: a required pointer is NULL";
+        case YH_ERR_SHAPE:
+            return "yolo_head: shape out of range (need batch >= 0, 1 <= S <= 64, 1 <= Bx <= 16, "
+                   "1 <= C <= 4096, img_size a positive multiple of S)";
+        case YH_ERR_WORKSPACE: return "yolo_head: workspace missing or too small";
+        case YH_ERR_ALIGN: return "yolo_head: pointer not aligned as documented";
+        case YH_ERR_ARG: return "yolo_head: invalid scalar argument";
+        case YH_ERR_UNSUPPORTED: return "yolo_head: more than 1024 candidates per image";
+        default: break;
+    }
+    if (rc > 0) return hipGetErrorString((hipError_t)rc);
+    return "yolo_head: unknown error code";
+}
+
+size_t yh_workspace_bytes(int op, int64_t batch, int S, int Bx, int C) {
+    (void)Bx; (void)C;
+    if (op != YH_OP_LOSS || batch < 0 || S < 1 || S > YH_MAX_S) return 0;
+    const int64_t rows = loss_blocks(batch, S);
+    return (size_t)(rows < 1 ? 1 : rows) * 4 * sizeof(float);
+}
+
+int yh_loss_fwd_bwd(const float* pred, const float* gt_xywh, const float* gt_cls,
+                    const uint8_t* obj_mask, float* grad_pred, float* loss_terms,
+                    void* workspace, size_t workspace_bytes, int64_t batch, int S, int Bx,
+                    int C, int img_size, float lambda_coord, float lambda_noobj,
+                    float inv_global_batch, void* stream) {
+    if (const int rc = check_shape(batch, S, Bx, C, img_size)) return rc;
+    if (!loss_terms || !workspace) return !workspace ? YH_ERR_WORKSPACE : YH_ERR_NULL;
+    if (batch > 0 && (!pred || !gt_xywh || !gt_cls || !obj_mask || !grad_pred)) return YH_ERR_NULL;
+    if (workspace_bytes < yh_workspace_bytes(YH_OP_LOSS, batch, S, Bx, C)) return YH_ERR_WORKSPACE;
+    if (!aligned(workspace, 16) || !aligned(gt_xywh, 16) || !aligned(pred, 4) ||
+        !aligned(grad_pred, 4) || !aligned(gt_cls, 4) || !aligned(loss_terms, 4))
+        return YH_ERR_ALIGN;
+    if (isnan(lambda_coord) || isnan(lambda_noobj) || isnan(inv_global_batch)) return YH_ERR_ARG;
+
+    hipStream_t st = (hipStream_t)stream;
+    float* partials = (float*)workspace;
+    const int64_t rows = loss_blocks(batch, S);
+    const int g = loss_imgs_per_block(S);
+    const float cellf = (float)(img_size / S);
+    const float imgf = (float)img_size;
+    if (rows > 0) {
+        const bool fast = Bx == 2 && C == 20 && aligned(gt_cls, 16);
+        if (fast) {
+            hipLaunchKernelGGL((yh::loss_fwd_bwd_kernel<2, 20>), dim3((unsigned)rows),
+                               dim3(yh::LOSS_THREADS), 0, st, pred, gt_xywh, gt_cls, obj_mask,
+                               grad_pred, partials, (long long)batch, S, Bx, C, g, cellf, imgf,
+                               lambda_coord, lambda_noobj, inv_global_batch);
+        } else {
+            hipLaunchKernelGGL((yh::loss_fwd_bwd_kernel<0, 0>), dim3((unsigned)rows),
+                               dim3(yh::LOSS_THREADS), 0, st, pred, gt_xywh, gt_cls, obj_mask,
+                               grad_pred, partials, (long long)batch, S, Bx, C, g, cellf, imgf,
+                               lambda_coord, lambda_noobj, inv_global_batch);
+        }
+        if (const int rc = launch_status()) return rc;
+    }
+    hipLaunchKernelGGL(yh::loss_finalize_kernel, dim3(1), dim3(256), 0, st, partials, (int)rows,
+                       inv_global_batch, loss_terms);
+    return launch_status();
+}
+
+int yh_scale_grad(float* grad, const float* scale, int64_t n, void* stream) {
+    if (n < 0) return YH_ERR_SHAPE;
+    if (n == 0) return YH_OK;
+    if (!grad || !scale) return YH_ERR_NULL;
+    if (!aligned(grad, 16) || !aligned(scale, 4)) return YH_ERR_ALIGN;
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(yh::scale_grad_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, grad, scale, (long long)n);
+    return launch_status();
+}
+
+int yh_decode_grid(const float* pred, float* ltrb, float* conf, float* cls_prob,
+                   int64_t* cls_idx, int64_t* best_k, float* best_ltrb, uint8_t* conf_mask,
+                   float conf_thresh, int64_t batch, int S, int Bx, int C, int img_size,
+                   void* stream) {
+    if (const int rc = check_shape(batch, S, Bx, C, img_size)) return rc;
+    if (batch == 0) return YH_OK;
+    if (!pred) return YH_ERR_NULL;
+    if (!aligned(pred, 4) || !aligned(ltrb, 16) || !aligned(best_ltrb, 16) ||
+        !aligned(cls_idx, 8) || !aligned(best_k, 8) || !aligned(conf, 4) || !aligned(cls_prob, 4))
+        return YH_ERR_ALIGN;
+    if (conf_mask && isnan(conf_thresh)) return YH_ERR_ARG;
+    const int64_t total = batch * S * S;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(yh::decode_grid_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, pred, ltrb, conf, cls_prob, (long long*)cls_idx,
+                       (long long*)best_k, best_ltrb, conf_mask, conf_thresh, (long long)batch,
+                       S, Bx, C, (float)(img_size / S), (float)img_size);
+    return launch_status();
+}
+
+int yh_decode_candidates(const float* pred, float* cand_ltrb, float* cand_score,
+                         int32_t* cand_cls, uint8_t* cand_present, int mode, int64_t batch,
+                         int S, int Bx, int C, int img_size, void* stream) {
+    if (const int rc = check_shape(batch, S, Bx, C, img_size)) return rc;
+    if (mode != YH_MODE_REFERENCE && mode != YH_MODE_DENSE) return YH_ERR_ARG;
+    if (batch == 0) return YH_OK;
+    if (!pred || !cand_ltrb || !cand_score || !cand_cls || !cand_present) return YH_ERR_NULL;
+    if (!aligned(pred, 4) || !aligned(cand_ltrb, 16) || !aligned(cand_score, 4) ||
+        !aligned(cand_cls, 4))
+        return YH_ERR_ALIGN;
+    const int64_t total = batch * S * S;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(yh::decode_candidates_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, pred, cand_ltrb, cand_score, cand_cls, cand_present,
+                       (long long)batch, S, Bx, C, mode, (float)(img_size / S), (float)img_size);
+    return launch_status();
+}
+
+int yh_decode_nms(const float* pred, float* dets, int32_t* keep_count, int32_t* keep_idx,
+                  int mode, float conf_thresh, float iou_thresh, int64_t batch, int S, int Bx,
+                  int C, int img_size, void* stream) {
+    if (const int rc = check_shape(batch, S, Bx, C, img_size)) return rc;
+    if (mode != YH_MODE_REFERENCE && mode != YH_MODE_DENSE) return YH_ERR_ARG;
+    if (isnan(conf_thresh) || isnan(iou_thresh)) return YH_ERR_ARG;
+    if ((int64_t)S * S * Bx > YH_MAX_CANDIDATES) return YH_ERR_UNSUPPORTED;
+    if (batch == 0) return YH_OK;
+    if (!pred || !dets || !keep_count) return YH_ERR_NULL;
+    if (!aligned(pred, 4) || !aligned(dets, 4) || !aligned(keep_count, 4) || !aligned(keep_idx, 4))
+        return YH_ERR_ALIGN;
+    yh::NmsArgs a = {};
+    a.pred = pred;
+    a.dets = dets;
+    a.keep_count = keep_count;
+    a.keep_idx = keep_idx;
+    a.batch = batch;
+    a.S = S; a.nb = Bx; a.nc = C; a.mode = mode;
+    a.nslot = mode == YH_MODE_REFERENCE ? S * S : S * S * Bx;
+    a.nout = S * S * Bx;
+    a.cellf = (float)(img_size / S);
+    a.imgf = (float)img_size;
+    a.conf_thr = conf_thresh;
+    a.iou_thr = iou_thresh;
+    return launch_nms<0>(a, (hipStream_t)stream);
+}
+
+int yh_nms(const float* cand_ltrb, const float* cand_score, const int32_t* cand_cls,
+           const uint8_t* cand_present, float* dets, int32_t* keep_count, int32_t* keep_idx,
+           float conf_thresh, float iou_thresh, int64_t batch, int N, void* stream) {
+    if (batch < 0 || N < 1) return YH_ERR_SHAPE;
+    if (N > YH_MAX_CANDIDATES) return YH_ERR_UNSUPPORTED;
+    if (isnan(conf_thresh) || isnan(iou_thresh)) return YH_ERR_ARG;
+    if (batch == 0) return YH_OK;
+    if (!cand_ltrb || !cand_score || !cand_cls || !dets || !keep_count) return YH_ERR_NULL;
+    if (!aligned(cand_ltrb, 16) || !aligned(cand_score, 4) || !aligned(cand_cls, 4) ||
+        !aligned(dets, 4) || !aligned(keep_count, 4) || !aligned(keep_idx, 4))
+        return YH_ERR_ALIGN;
+    yh::NmsArgs a = {};
+    a.c_ltrb = cand_ltrb;
+    a.c_score = cand_score;
+    a.c_cls = cand_cls;
+    a.c_present = cand_present;
+    a.dets = dets;
+    a.keep_count = keep_count;
+    a.keep_idx = keep_idx;
+    a.batch = batch;
+    a.S = 1; a.nb = 1; a.nc = 1; a.mode = YH_MODE_DENSE;
+    a.nslot = N;
+    a.nout = N;
+    a.conf_thr = conf_thresh;
+    a.iou_thr = iou_thresh;
+    return launch_nms<1>(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,303 @@
+"""YOLOv1 detection head on MI355X: the reference's head methods
+(model.py:150-317, 379-394) backed by the HIP kernels of libyolohead.so.
+
+``YOLOv1Head`` keeps the reference's names, argument meaning and constructor
+keywords (model.py:96-104), so a caller written against ``YOLOv1`` keeps
+working:
+
+    head = YOLOv1Head()                       # or YOLOv1Head(backbone=net)
+    loss = head.get_loss(out, gt_norm_xywh, gt_cls_prob, obj_mask)
+    loss.backward()                           # or scaler.scale(loss).backward()
+    dets, count = head.postprocess(out, conf_thresh=0.5, iou_thresh=0.5)
+
+Tensors stay on the GPU; PyTorch supplies memory and the current stream only.
+Every op raises if the HIP library is missing -- there is no fallback path.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+from torch import nn
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _need(t: torch.Tensor, name: str, dtype, shape=None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise ValueError(f"{name}: must live on the GPU (got device {t.device}); "
+                         "yolo_amd has no CPU path")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+class _LossFunction(torch.autograd.Function):
+    """Forward launches the fused forward+backward kernel and keeps the
+    gradient; backward hands it out, multiplied on the device by the incoming
+    grad_output (1 for ``loss.backward()``, the GradScaler scale under
+    ``scaler.scale(loss).backward()``, train.py:88-93)."""
+
+    @staticmethod
+    def forward(ctx, out, gt_norm_xywh, gt_cls_prob, obj_mask, head, inv_global_batch):
+        terms, grad = head._launch_loss(out, gt_norm_xywh, gt_cls_prob, obj_mask, inv_global_batch)
+        ctx.grad_pred = grad
+        head.last_loss_terms = terms
+        return terms[4]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        grad = ctx.grad_pred
+        ctx.grad_pred = None
+        if grad is None:
+            raise RuntimeError("YOLOv1Head loss: backward called twice; the fused kernel keeps "
+                               "one gradient buffer per forward")
+        go = grad_output
+        if go.dtype != torch.float32 or go.numel() != 1 or go.device != grad.device:
+            go = go.to(device=grad.device, dtype=torch.float32).reshape(())
+        with torch.cuda.device(grad.device):
+            _lib.check(_lib.load().yh_scale_grad(grad.data_ptr(), go.data_ptr(), grad.numel(),
+                                                 _stream(grad.device)))
+        return grad, None, None, None, None, None
+
+
+class YOLOv1Head(nn.Module):
+    def __init__(
+        self,
+        img_size: int = 448,
+        n_cells: int = 7,
+        n_bboxes: int = 2,
+        n_classes: int = 20,
+        coord_coeff: float = 5,
+        noobj_coeff: float = 0.5,
+        backbone: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
+    ):
+        super().__init__()
+        self.img_size = int(img_size)
+        self.n_cells = int(n_cells)
+        self.n_bboxes = int(n_bboxes)
+        self.n_classes = int(n_classes)
+        self.coord_coeff = float(coord_coeff)
+        self.noobj_coeff = float(noobj_coeff)
+        self.cell_size = self.img_size // self.n_cells           # model.py:114
+        self.backbone = backbone
+        self.last_loss_terms: Optional[torch.Tensor] = None
+        self._workspace = {}
+        _lib.load()  # fail at construction time if the HIP library is missing
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def depth(self) -> int:
+        return 5 * self.n_bboxes + self.n_classes
+
+    @property
+    def n_grid(self) -> int:
+        return self.n_cells * self.n_cells
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """The head tensor (B, 5*Bx+C, S, S) of model.py:139-148: ``backbone(x)``
+        reshaped, or ``x`` itself when no backbone is attached."""
+        out = self.backbone(x) if self.backbone is not None else x
+        return out.view(-1, self.depth, self.n_cells, self.n_cells)
+
+    def _check_out(self, out: torch.Tensor) -> torch.Tensor:
+        if not isinstance(out, torch.Tensor):
+            raise TypeError(f"out: expected a torch.Tensor, got {type(out).__name__}")
+        if out.dim() != 4 or tuple(out.shape[1:]) != (self.depth, self.n_cells, self.n_cells):
+            raise ValueError(f"out: expected shape (B, {self.depth}, {self.n_cells}, "
+                             f"{self.n_cells}), got {tuple(out.shape)}")
+        return _need(out, "out", torch.float32)
+
+    def _get_workspace(self, device, nbytes: int) -> torch.Tensor:
+        ws = self._workspace.get(device)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(max(nbytes, 4096), dtype=torch.uint8, device=device)
+            self._workspace[device] = ws
+        return ws
+
+    # --------------------------------------------------------------------- loss
+    def _launch_loss(self, out, gt_norm_xywh, gt_cls_prob, obj_mask, inv_global_batch):
+        out = self._check_out(out)
+        bsz, n = out.shape[0], self.n_grid
+        _need(gt_norm_xywh, "gt_norm_xywh", torch.float32, (bsz, n, 1, 4))
+        _need(gt_cls_prob, "gt_cls_prob", torch.float32, (bsz, n, 1, self.n_classes))
+        if obj_mask.dtype == torch.bool:
+            obj_mask = obj_mask.view(torch.uint8)
+        _need(obj_mask, "obj_mask", torch.uint8, (bsz, n, 1, 1))
+        for name, t in (("gt_norm_xywh", gt_norm_xywh), ("gt_cls_prob", gt_cls_prob),
+                        ("obj_mask", obj_mask)):
+            if t.device != out.device:
+                raise ValueError(f"{name}: on {t.device}, out is on {out.device}")
+        lib = _lib.load()
+        nbytes = lib.yh_workspace_bytes(_lib.YH_OP_LOSS, bsz, self.n_cells, self.n_bboxes,
+                                        self.n_classes)
+        ws = self._get_workspace(out.device, nbytes)
+        grad = torch.empty_like(out)
+        terms = torch.empty(5, dtype=torch.float32, device=out.device)
+        with torch.cuda.device(out.device):
+            _lib.check(lib.yh_loss_fwd_bwd(
+                out.data_ptr(), gt_norm_xywh.data_ptr(), gt_cls_prob.data_ptr(),
+                obj_mask.data_ptr(), grad.data_ptr(), terms.data_ptr(), ws.data_ptr(),
+                ws.numel(), bsz, self.n_cells, self.n_bboxes, self.n_classes, self.img_size,
+                self.coord_coeff, self.noobj_coeff, float(inv_global_batch),
+                _stream(out.device)))
+        return terms, grad
+
+    def loss_fwd_bwd(self, out, gt_norm_xywh, gt_cls_prob, obj_mask, global_batch=None):
+        """Functional form: one kernel pass returning ``(terms, grad)`` with
+        terms = [coord_sum, conf_sum, cls_sum, total_sum, total/global_batch] and
+        grad = d(total/global_batch)/d(out).  No autograd graph is recorded."""
+        gb = out.shape[0] if global_batch is None else int(global_batch)
+        return self._launch_loss(out.detach(), gt_norm_xywh, gt_cls_prob, obj_mask,
+                                 1.0 / max(gb, 1))
+
+    def get_loss(self, image, gt_norm_xywh, gt_cls_prob, obj_mask, global_batch=None):
+        """model.py:296-317: (coord + conf + cls) / B as a 0-d tensor that supports
+        ``.backward()``.  ``image`` goes through the attached backbone; without
+        one it is taken as the head tensor itself.  ``global_batch`` replaces B
+        when this call sees one shard of a data-parallel batch (the shard losses
+        then add up to the global loss)."""
+        out = self(image)
+        gb = out.shape[0] if global_batch is None else int(global_batch)
+        inv = 1.0 / max(gb, 1)
+        if torch.is_grad_enabled() and out.requires_grad:
+            return _LossFunction.apply(out, gt_norm_xywh, gt_cls_prob, obj_mask, self, inv)
+        terms, _ = self._launch_loss(out.detach(), gt_norm_xywh, gt_cls_prob, obj_mask, inv)
+        self.last_loss_terms = terms
+        return terms[4]
+
+    # ------------------------------------------------------------------- decode
+    def _decode(self, out, want, conf_thresh=0.0):
+        out = self._check_out(out.detach())
+        bsz, n, dev = out.shape[0], self.n_grid, out.device
+        res = {}
+        if "ltrb" in want:
+            res["ltrb"] = torch.empty(bsz, n, self.n_bboxes, 4, dtype=torch.float32, device=dev)
+        if "conf" in want:
+            res["conf"] = torch.empty(bsz, n, self.n_bboxes, 1, dtype=torch.float32, device=dev)
+        if "cls_prob" in want:
+            res["cls_prob"] = torch.empty(bsz, n, 1, self.n_classes, dtype=torch.float32, device=dev)
+        if "cls_idx" in want:
+            res["cls_idx"] = torch.empty(bsz, n, 1, 1, dtype=torch.int64, device=dev)
+        if "best_k" in want:
+            res["best_k"] = torch.empty(bsz, n, 1, 1, dtype=torch.int64, device=dev)
+        if "best_ltrb" in want:
+            res["best_ltrb"] = torch.empty(bsz, n, 1, 4, dtype=torch.float32, device=dev)
+        if "conf_mask" in want:
+            res["conf_mask"] = torch.empty(bsz, n, 1, 1, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().yh_decode_grid(
+                out.data_ptr(), _ptr(res.get("ltrb")), _ptr(res.get("conf")),
+                _ptr(res.get("cls_prob")), _ptr(res.get("cls_idx")), _ptr(res.get("best_k")),
+                _ptr(res.get("best_ltrb")), _ptr(res.get("conf_mask")), float(conf_thresh),
+                bsz, self.n_cells, self.n_bboxes, self.n_classes, self.img_size, _stream(dev)))
+        return res
+
+    def get_ltrb(self, out):
+        """model.py:185-188, batched: (B, S*S, Bx, 4) pixel boxes."""
+        return self._decode(out, ("ltrb",))["ltrb"]
+
+    def get_confidence(self, out):
+        """model.py:242-250: (B, S*S, Bx, 1)."""
+        return self._decode(out, ("conf",))["conf"]
+
+    def get_classification_prob(self, out):
+        """model.py:278-286: (B, S*S, 1, C) softmax."""
+        return self._decode(out, ("cls_prob",))["cls_prob"]
+
+    def _get_classification_index(self, out):
+        """model.py:392-394: (B, S*S, 1, 1) int64."""
+        return self._decode(out, ("cls_idx",))["cls_idx"]
+
+    def get_confidence_mask(self, out, conf_thresh):
+        """model.py:379-382: (B, S*S, 1, 1) bool, max_k conf >= conf_thresh."""
+        return self._decode(out, ("conf_mask",), conf_thresh)["conf_mask"].view(torch.bool)
+
+    def get_max_confidence_ltrb(self, out):
+        """model.py:384-390: (B, S*S, 1, 4) box of the higher-confidence predictor."""
+        return self._decode(out, ("best_ltrb",))["best_ltrb"]
+
+    # ---------------------------------------------------------------------- NMS
+    def decode_candidates(self, out, mode=_lib.YH_MODE_REFERENCE):
+        """The NMS candidates of ``postprocess`` as tensors: ltrb (B, N, 4),
+        score (B, N), cls (B, N) int32, present (B, N) bool; N = S*S*Bx."""
+        out = self._check_out(out.detach())
+        bsz, nn_, dev = out.shape[0], self.n_grid * self.n_bboxes, out.device
+        ltrb = torch.empty(bsz, nn_, 4, dtype=torch.float32, device=dev)
+        score = torch.empty(bsz, nn_, dtype=torch.float32, device=dev)
+        cls = torch.empty(bsz, nn_, dtype=torch.int32, device=dev)
+        present = torch.empty(bsz, nn_, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().yh_decode_candidates(
+                out.data_ptr(), ltrb.data_ptr(), score.data_ptr(), cls.data_ptr(),
+                present.data_ptr(), int(mode), bsz, self.n_cells, self.n_bboxes, self.n_classes,
+                self.img_size, _stream(dev)))
+        return ltrb, score, cls, present.view(torch.bool)
+
+    def postprocess(self, out, conf_thresh=0.5, iou_thresh=0.5, mode=_lib.YH_MODE_REFERENCE,
+                    return_idx=False):
+        """Decode + confidence threshold + per-class NMS in one kernel.
+
+        Returns dets (B, S*S*Bx, 6) with the kept rows ``l, t, r, b, conf, class``
+        first (the row layout eval.py:89-91 consumes; class ascending, then
+        confidence descending) and zero rows after them, keep_count (B,) int32,
+        and with ``return_idx`` keep_idx (B, S*S*Bx) int32 (flat index
+        cell*Bx + k of each kept row, -1 padding)."""
+        out = self._check_out(out.detach())
+        bsz, nn_, dev = out.shape[0], self.n_grid * self.n_bboxes, out.device
+        dets = torch.empty(bsz, nn_, 6, dtype=torch.float32, device=dev)
+        count = torch.empty(bsz, dtype=torch.int32, device=dev)
+        kidx = torch.empty(bsz, nn_, dtype=torch.int32, device=dev) if return_idx else None
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().yh_decode_nms(
+                out.data_ptr(), dets.data_ptr(), count.data_ptr(), _ptr(kidx), int(mode),
+                float(conf_thresh), float(iou_thresh), bsz, self.n_cells, self.n_bboxes,
+                self.n_classes, self.img_size, _stream(dev)))
+        return (dets, count, kidx) if return_idx else (dets, count)
+
+    @staticmethod
+    def nms(ltrb, score, cls, present=None, conf_thresh=0.0, iou_thresh=0.5, return_idx=False):
+        """Per-class NMS over caller-supplied candidates: ltrb (B, N, 4) f32,
+        score (B, N) f32, cls (B, N) int32, present (B, N) bool or None."""
+        _need(ltrb, "ltrb", torch.float32)
+        bsz, n = ltrb.shape[0], ltrb.shape[1]
+        _need(ltrb, "ltrb", torch.float32, (bsz, n, 4))
+        _need(score, "score", torch.float32, (bsz, n))
+        _need(cls, "cls", torch.int32, (bsz, n))
+        if present is not None:
+            if present.dtype == torch.bool:
+                present = present.view(torch.uint8)
+            _need(present, "present", torch.uint8, (bsz, n))
+        dev = ltrb.device
+        dets = torch.empty(bsz, n, 6, dtype=torch.float32, device=dev)
+        count = torch.empty(bsz, dtype=torch.int32, device=dev)
+        kidx = torch.empty(bsz, n, dtype=torch.int32, device=dev) if return_idx else None
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().yh_nms(
+                ltrb.data_ptr(), score.data_ptr(), cls.data_ptr(), _ptr(present),
+                dets.data_ptr(), count.data_ptr(), _ptr(kidx), float(conf_thresh),
+                float(iou_thresh), bsz, n, _stream(dev)))
+        return (dets, count, kidx) if return_idx else (dets, count)
+
+    def detections(self, out, conf_thresh=0.5, iou_thresh=0.5, mode=_lib.YH_MODE_REFERENCE):
+        """Host-side convenience: a list with one (n_i, 6) tensor per image -- the
+        ``pred`` argument of eval.get_map (eval.py:86-94).  Synchronises."""
+        dets, count = self.postprocess(out, conf_thresh, iou_thresh, mode)
+        counts = count.tolist()
+        return [dets[b, :k] for b, k in enumerate(counts)]
