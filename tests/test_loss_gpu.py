@@ -126,7 +126,21 @@ def test_extreme_logits_and_degenerate_boxes(dev):
         pred[4, 0:4, c // 7, c % 7] = torch.log(g / (1 - g))
     terms, grad = run_hip(head, dev, pred, gx, gc, om)
     assert torch.isfinite(grad).all() and torch.isfinite(terms).all()
-    check_against_oracle(terms, grad, ref_cpu.loss_and_grad(pred, gx, gc, om))
+    ref = ref_cpu.loss_and_grad(pred, gx, gc, om)
+    # The reference's graph computes IoU for EVERY cell and masks afterwards by
+    # multiplication.  A zero-area prediction against a zero-area (absent) ground
+    # truth makes union == 0; torch.where guards the forward value but its backward
+    # still forms 0 * (0/0) = NaN, so autograd returns NaN for the box logits of such
+    # cells although they carry no loss.  The kernel never evaluates IoU for a
+    # predictor that is not responsible and returns the masked value, 0, there.
+    bad = ~torch.isfinite(ref["grad"])
+    assert bad.any()                                   # the case is really exercised
+    assert (grad[bad] == 0).all()
+    box_channels = torch.zeros(30, dtype=torch.bool)
+    box_channels[[0, 1, 2, 3, 5, 6, 7, 8]] = True
+    assert not bad[:, ~box_channels].any()
+    ref["grad"] = torch.where(bad, torch.zeros_like(ref["grad"]), ref["grad"])
+    check_against_oracle(terms, grad, ref)
 
 
 def test_full_size_batch_4096(dev):
