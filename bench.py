@@ -1,0 +1,303 @@
+#!/usr/bin/env python3
+"""Headline benchmark: YOLOv1 head images/sec (loss fwd+bwd + decode/NMS).
+
+One "step" = one pass of the hot path over one batch that is already resident
+in HBM: the fused loss forward+backward (gradient w.r.t. the head tensor and
+the loss sums) followed by decode + confidence threshold + per-class NMS of the
+same head tensor.  Workload at one GPU: S=7, Bx=2, C=20, batch 4096, fp32,
+synthetic logits and targets (yolo_amd.synth).  With N GPUs every rank runs the
+same per-GPU batch on its own shard (weak scaling); the only exchange is the
+all-reduce of the per-step loss sums, batched over `--allreduce-every` steps and
+completed inside the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the
+fused loss kernel): algorithmic bytes per launch / its HIP-event duration,
+against the 8 TB/s HBM3E peak.  `cpu_baseline` is the CPU oracle (a port of the
+reference's formulas, oracle/ref_cpu.py) timed on this host on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (spec)
+S, BX, C, IMG = 7, 2, 20, 448
+CONF_T, IOU_T = 0.5, 0.5
+
+
+def loss_bytes_per_image(s=S, bx=BX, c=C):
+    """Algorithmic bytes of the fused loss kernel per image: head tensor read +
+    targets read (xywh, class probabilities, object mask) + gradient written."""
+    d, n = 5 * bx + c, s * s
+    return 4 * d * n + (n * (4 + c) * 4 + n) + 4 * d * n
+
+
+def nms_bytes_per_image(s=S, bx=BX, c=C):
+    """Algorithmic bytes of decode+NMS per image: head tensor read + detections
+    written (S*S*Bx rows of 6 floats) + keep count."""
+    d, n = 5 * bx + c, s * s
+    return 4 * d * n + 24 * n * bx + 4
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=4096, help="images per GPU")
+    ap.add_argument("--allreduce-every", type=int, default=32)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--kernel-iters", type=int, default=200)
+    return ap.parse_args()
+
+
+def time_kernel(fn, iters):
+    """Average duration of one launch of `fn` from HIP events recorded on the
+    launch stream around EACH launch, and the back-to-back rate of `iters` launches."""
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+    for i in range(iters):
+        starts[i].record()
+        fn()
+        stops[i].record()
+    torch.cuda.synchronize()
+    per = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return {
+        "avg_us": 1e3 * sum(per) / len(per),
+        "median_us": 1e3 * per[len(per) // 2],
+        "back_to_back_us": 1e3 * a.elapsed_time(b) / iters,
+    }
+
+
+def cpu_baseline(seconds, batch):
+    from oracle import ref_cpu
+    from yolo_amd import synth
+
+    n = min(1024, batch)
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    pred, gx, gc, om = synth.make_inputs(n, S, BX, C, IMG, seed=0)
+    ref_cpu.loss_and_grad(pred[:64], gx[:64], gc[:64], om[:64])   # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        ref_cpu.loss_and_grad(pred, gx, gc, om)
+        ref_cpu.postprocess(pred, CONF_T, IOU_T, mode=0)
+        reps += 1
+        el = time.perf_counter() - t0
+        if (el >= seconds and reps >= 2) or reps >= 50:
+            break
+    return {
+        "value": reps * n / el, "unit": "images/s", "cores": cores, "kind": "port",
+        "sample": f"{reps} passes over the first {n} images of the workload: PyTorch fp32 CPU "
+                  f"loss forward + autograd backward ({cores} threads) and single-threaded "
+                  f"numpy decode+NMS, {el:.1f} s",
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
+                             f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch.distributed as dist
+    from yolo_amd import MODE_REFERENCE, LossLog, YOLOv1Head, _lib, synth
+    from yolo_amd.dist import LossAllReducer
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    batch = args.batch
+    global_batch = batch * world
+    head = YOLOv1Head(IMG, S, BX, C)
+    pred, gx, gc, om = (t.to(dev) for t in synth.make_inputs(batch, S, BX, C, IMG, seed=2 * rank))
+    every = max(1, min(args.allreduce_every, 4096))
+    log = LossLog(dev, capacity=every)
+    reducer = LossAllReducer()
+
+    def step():
+        terms, grad = head.loss_fwd_bwd(pred, gx, gc, om, global_batch=global_batch, log=log)
+        dets, count = head.postprocess(pred, CONF_T, IOU_T, MODE_REFERENCE)
+        return terms, grad, dets, count
+
+    # ---- build the step: a HIP graph of its three kernels, or eager launches ----
+    graph, outs, use_graph = None, None, not args.no_graph
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            outs = step()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    if use_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = step()
+        except Exception as exc:  # capture unsupported: fall back to eager launches
+            if rank == 0:
+                print(f"[bench] graph capture failed ({exc!r}); running eagerly", file=sys.stderr)
+            graph, use_graph = None, False
+            torch.cuda.synchronize()
+
+    def run_step():
+        nonlocal outs
+        if graph is not None:
+            graph.replay()
+        else:
+            outs = step()
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        run_step()
+    torch.cuda.synchronize()
+    log.reset()
+
+    # ---- timed region: exactly K steps ------------------------------------------
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        run_step()
+        if (i + 1) % every == 0:
+            reducer.flush(log.ring, every)
+    reducer.flush(log.ring, args.steps % every)
+    losses = reducer.results()                      # waits for the collectives (stream-ordered)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    assert losses.shape == (args.steps, 4), losses.shape
+    loss_value = float(losses[-1, 3].item()) / global_batch
+    if not torch.isfinite(losses).all():
+        raise SystemExit("non-finite loss in the timed region")
+
+    value = args.steps * global_batch / elapsed
+    result = {
+        "metric": "YOLOv1 head images/sec (loss fwd+bwd + NMS)",
+        "value": value,
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"YOLOv1 head S={S},B={BX},C={C} batch {batch} per GPU fwd+bwd + NMS (fp32)",
+            "global_batch": global_batch,
+            "images_per_gpu": batch,
+            "conf_thresh": CONF_T, "iou_thresh": IOU_T, "nms_mode": "reference",
+            "parallelism": f"dp{world} by image, loss all-reduce every {every} steps",
+            "launch": "hip-graph" if use_graph else "eager",
+        },
+        "loss": loss_value,
+        "step_gbs": value * (loss_bytes_per_image() + nms_bytes_per_image()) / 1e9,
+    }
+
+    if rank == 0:
+        # ---- dominant kernel: HIP-event duration per launch -> roofline ----------
+        lib = _lib.load()
+        st = torch.cuda.current_stream(dev).cuda_stream
+        ws = head._get_workspace(dev, lib.yh_workspace_bytes(_lib.YH_OP_LOSS, batch, S, BX, C))
+        grad = torch.empty_like(pred)
+        om8 = om.view(torch.uint8)
+        dets = torch.empty(batch, S * S * BX, 6, device=dev)
+        cnt = torch.empty(batch, dtype=torch.int32, device=dev)
+        terms = torch.empty(5, device=dev)
+
+        def k_loss():
+            _lib.check(lib.yh_loss_partials(pred.data_ptr(), gx.data_ptr(), gc.data_ptr(),
+                                            om8.data_ptr(), grad.data_ptr(), ws.data_ptr(),
+                                            ws.numel(), batch, S, BX, C, IMG, 5.0, 0.5,
+                                            1.0 / global_batch, st))
+
+        def k_fin():
+            _lib.check(lib.yh_loss_finalize(ws.data_ptr(), ws.numel(), batch, S, 1.0 / global_batch,
+                                            terms.data_ptr(), None, 0, None, st))
+
+        def k_nms():
+            _lib.check(lib.yh_decode_nms(pred.data_ptr(), dets.data_ptr(), cnt.data_ptr(), None,
+                                         MODE_REFERENCE, CONF_T, IOU_T, batch, S, BX, C, IMG, st))
+
+        t_loss = time_kernel(k_loss, args.kernel_iters)
+        t_fin = time_kernel(k_fin, args.kernel_iters)
+        t_nms = time_kernel(k_nms, args.kernel_iters)
+        algo = loss_bytes_per_image() * batch
+        achieved = algo / (t_loss["avg_us"] * 1e-6) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("batch") == batch:
+                    traffic = tj.get("loss_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": "loss_fwd_bwd_kernel<2,20>",
+            "algorithmic_bytes_per_launch": algo,
+            "kernel_us": t_loss["avg_us"],
+        }
+        nms_algo = nms_bytes_per_image() * batch
+        result["kernels"] = {
+            "loss_fwd_bwd": t_loss, "loss_finalize": t_fin, "decode_nms": t_nms,
+            "decode_nms_gbs": nms_algo / (t_nms["avg_us"] * 1e-6) / 1e9,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_seconds, batch)
+        print(json.dumps(result), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -88,6 +88,30 @@ int yh_loss_fwd_bwd(const float* pred, const float* gt_xywh, const float* gt_cls
                     float inv_global_batch, void* stream);
 
 /*
+ * The two halves of yh_loss_fwd_bwd as separate launches, for callers that put
+ * the scalar reduction on another stream (nothing downstream of the gradient
+ * depends on it) or log the loss on the device.
+ *
+ * yh_loss_partials: everything yh_loss_fwd_bwd does except the final sum; one
+ * row of four floats per workgroup is left in `workspace`.
+ * yh_loss_finalize: adds those rows in a fixed order and writes loss_terms[5]
+ * as yh_loss_fwd_bwd does (same batch and S as the yh_loss_partials call).  If
+ * log_ring is not NULL it also appends the four sums to a device-side ring:
+ * row (*log_cursor % log_capacity) of log_ring (log_capacity, 4) receives
+ * coord, conf, class, total, then *log_cursor is incremented.  The cursor lives
+ * on the device, so a captured graph can be replayed and still log every step.
+ * No counterpart in the reference, which prints the terms (model.py:316).
+ */
+int yh_loss_partials(const float* pred, const float* gt_xywh, const float* gt_cls,
+                     const uint8_t* obj_mask, float* grad_pred, void* workspace,
+                     size_t workspace_bytes, int64_t batch, int S, int Bx, int C, int img_size,
+                     float lambda_coord, float lambda_noobj, float inv_global_batch,
+                     void* stream);
+int yh_loss_finalize(const void* workspace, size_t workspace_bytes, int64_t batch, int S,
+                     float inv_global_batch, float* loss_terms, float* log_ring,
+                     int log_capacity, int32_t* log_cursor, void* stream);
+
+/*
  * grad[i] *= *scale for i < n, in place; does not touch memory when *scale == 1.
  * `scale` is a device scalar: the grad_output that reaches the head's backward
  * (1 for loss.backward(), the GradScaler scale for

@@ -19,33 +19,35 @@ __global__ __launch_bounds__(256) void decode_grid_kernel(
         const long long img = g / S2;
         const int cell = (int)(g - img * S2);
         const float* p = pred + img * D * S2 + cell;
+        const MemLogits logit{p, S2};
         if (ltrb || conf) {
             for (int k = 0; k < nb; ++k) {
                 if (ltrb) {
-                    const Box b = cell_box(p, k, cell, S, S2, cellf, imgf);
+                    const Box b = cell_box(logit, k, cell, S, cellf, imgf);
                     reinterpret_cast<float4*>(ltrb)[g * nb + k] = make_float4(b.l, b.t, b.r, b.b);
                 }
-                if (conf) conf[g * nb + k] = sigmoidf_(p[(5 * k + 4) * S2]);
+                if (conf) conf[g * nb + k] = sigmoidf_(logit(5 * k + 4));
             }
         }
         if (best_k || best_ltrb || conf_mask) {
             float cb;
-            const int k = cell_best_conf(p, nb, S2, cb);
+            const int k = cell_best_conf(logit, nb, cb);
             if (best_k) best_k[g] = k;
             if (best_ltrb) {
-                const Box b = cell_box(p, k, cell, S, S2, cellf, imgf);
+                const Box b = cell_box(logit, k, cell, S, cellf, imgf);
                 reinterpret_cast<float4*>(best_ltrb)[g] = make_float4(b.l, b.t, b.r, b.b);
             }
             if (conf_mask) conf_mask[g] = cb >= conf_thresh ? 1 : 0;
         }
-        if (cls_idx) cls_idx[g] = cell_class(p, 5 * nb, nc, S2);
+        if (cls_idx) cls_idx[g] = cell_class_mem(p, 5 * nb, nc, S2);
         if (cls_prob) {
             const float* pc = p + 5 * nb * S2;
             float m = pc[0];
             for (int j = 1; j < nc; ++j) m = fmaxf(m, pc[j * S2]);
             float s = 0.f;
-            for (int j = 0; j < nc; ++j) s += expf(pc[j * S2] - m);
-            for (int j = 0; j < nc; ++j) cls_prob[g * nc + j] = expf(pc[j * S2] - m) / s;
+            for (int j = 0; j < nc; ++j) s += exp_fast(pc[j * S2] - m);
+            const float rs = rcp_fast(s);
+            for (int j = 0; j < nc; ++j) cls_prob[g * nc + j] = exp_fast(pc[j * S2] - m) * rs;
         }
     }
 }

@@ -27,10 +27,12 @@ __device__ __forceinline__ void loss_cell(const float* __restrict__ p, float* __
     const int nc = C_CT > 0 ? C_CT : nc_rt;
     constexpr bool kStatic = BX_CT > 0 && C_CT > 0;
     constexpr int kD = kStatic ? 5 * BX_CT + C_CT : 1;
+    const int c0 = 5 * nb;
 
     // Compile-time shape: all D logits of the cell are fetched up front, with no
-    // dependence on obj_mask, so the whole cell costs one memory round trip; the
-    // lines are needed by neighbouring cells anyway.  Run-time shape: read on use.
+    // dependence on obj_mask, so the cell costs one memory round trip (plus one
+    // for the ground truth of an object cell); the lines are needed by
+    // neighbouring cells anyway.  Run-time shape: read on use.
     float v[kD];
     if constexpr (kStatic) {
 #pragma unroll
@@ -41,43 +43,78 @@ __device__ __forceinline__ void loss_cell(const float* __restrict__ p, float* __
         else return p[ch * S2];
     };
 
-    int best = 0;
-    float bnx = 0.f, bny = 0.f, bnw = 0.f, bnh = 0.f, biou = 0.f;
-    float gnx = 0.f, gny = 0.f, gnw = 0.f, gnh = 0.f;
-    float xoff = 0.f, yoff = 0.f;
-    Box gbox = {0.f, 0.f, 0.f, 0.f};
-    if (obj) {
-        // ground truth through the same decode as the predictions (model.py:261-262)
-        const float4 gv = *reinterpret_cast<const float4*>(gxywh);
-        gnx = gv.x; gny = gv.y; gnw = gv.z; gnh = gv.w;
-        xoff = cellf * (float)(cell / S);   // first spatial axis carries x (model.py:175-177)
-        yoff = cellf * (float)(cell % S);
-        gbox = decode_box(gnx, gny, gnw, gnh, xoff, yoff, cellf, imgf);
-        // responsible predictor: highest IoU, first index on ties (model.py:210)
+    if (!obj) {
+        // a cell without object: only the no-object confidence term (model.py:270-274)
 #pragma unroll
         for (int k = 0; k < nb; ++k) {
-            const float nx = sigmoidf_(logit(5 * k + 0));
-            const float ny = sigmoidf_(logit(5 * k + 1));
-            const float nw = sigmoidf_(logit(5 * k + 2));
-            const float nh = sigmoidf_(logit(5 * k + 3));
-            const float iou = iou_pair(decode_box(nx, ny, nw, nh, xoff, yoff, cellf, imgf), gbox);
-            if (k == 0 || iou > biou) {
-                best = k; biou = iou; bnx = nx; bny = ny; bnw = nw; bnh = nh;
-            }
+            const float conf = sigmoidf_(logit(5 * k + 4));
+            acc_conf += ln * (conf * conf);
+            g[(5 * k + 0) * S2] = 0.0f;
+            g[(5 * k + 1) * S2] = 0.0f;
+            g[(5 * k + 2) * S2] = 0.0f;
+            g[(5 * k + 3) * S2] = 0.0f;
+            g[(5 * k + 4) * S2] = 2.0f * ln * conf * (conf * (1.0f - conf)) * inv_gb;
         }
+#pragma unroll
+        for (int j = 0; j < nc; ++j) g[(c0 + j) * S2] = 0.0f;
+        return;
+    }
+
+    // ---- object cell ------------------------------------------------------------
+    // ground truth through the same decode as the predictions (model.py:261-262)
+    const float4 gv = *reinterpret_cast<const float4*>(gxywh);
+    float gtc[C_CT > 0 ? C_CT : 1];
+    if constexpr (C_CT > 0 && C_CT % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < C_CT / 4; ++j) {
+            const float4 q = reinterpret_cast<const float4*>(gcls)[j];
+            gtc[4 * j] = q.x; gtc[4 * j + 1] = q.y; gtc[4 * j + 2] = q.z; gtc[4 * j + 3] = q.w;
+        }
+    }
+    auto gtcls = [&](int j) -> float {
+        if constexpr (C_CT > 0 && C_CT % 4 == 0) return gtc[j];
+        else return gcls[j];
+    };
+    const float gnx = gv.x, gny = gv.y, gnw = gv.z, gnh = gv.w;
+    const float xoff = cellf * (float)(cell / S);   // first spatial axis carries x (model.py:175-177)
+    const float yoff = cellf * (float)(cell % S);
+    const Box gbox = decode_box(gnx, gny, gnw, gnh, xoff, yoff, cellf, imgf);
+
+    // responsible predictor: highest IoU, first index on ties (model.py:210)
+    int best = 0;
+    float bnx = 0.f, bny = 0.f, bnw = 0.f, bnh = 0.f, biou = 0.f;
+#pragma unroll
+    for (int k = 0; k < nb; ++k) {
+        const float nx = sigmoidf_(logit(5 * k + 0));
+        const float ny = sigmoidf_(logit(5 * k + 1));
+        const float nw = sigmoidf_(logit(5 * k + 2));
+        const float nh = sigmoidf_(logit(5 * k + 3));
+        const float iou = iou_pair_fast(decode_box(nx, ny, nw, nh, xoff, yoff, cellf, imgf), gbox);
+        if (k == 0 || iou > biou) {
+            best = k; biou = iou; bnx = nx; bny = ny; bnw = nw; bnh = nh;
+        }
+    }
+
+    // gradients of the responsible predictor's box (model.py:224-240, 267-269)
+    float r0, r1, r2, r3;
+    {
+        const float dx = bnx - gnx, dy = bny - gny;
+        const float sw = __builtin_amdgcn_sqrtf(bnw), sh = __builtin_amdgcn_sqrtf(bnh);
+        const float dw = sw - __builtin_amdgcn_sqrtf(gnw), dh = sh - __builtin_amdgcn_sqrtf(gnh);
+        acc_coord += lc * ((dx * dx + dy * dy) + (dw * dw + dh * dh));
+        r0 = 2.0f * lc * dx;
+        r1 = 2.0f * lc * dy;
+        // d/dn of lc*(sqrt(n) - sqrt(g))^2 times sigmoid' = lc*(sw - sg)*sw*(1 - n)
+        r2 = lc * dw * sw * (1.0f - bnw);
+        r3 = lc * dh * sh * (1.0f - bnh);
     }
 
 #pragma unroll
     for (int k = 0; k < nb; ++k) {
         const float conf = sigmoidf_(logit(5 * k + 4));
         float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, gc;
-        if (obj && k == best) {
-            // coordinate term (model.py:224-240)
-            const float dx = bnx - gnx, dy = bny - gny;
-            const float sw = sqrtf(bnw), sh = sqrtf(bnh);
-            const float dw = sw - sqrtf(gnw), dh = sh - sqrtf(gnh);
-            acc_coord += lc * ((dx * dx + dy * dy) + (dw * dw + dh * dh));
-            // objectness term (model.py:267-269); IoU is part of the graph
+        if (k == best) {
+            // objectness term; IoU is part of the graph (model.py:263-269)
             const float dc = conf - biou;
             acc_conf += dc * dc;
             float ul, ut, ur, ub, gl, gt, gr, gb;
@@ -92,14 +129,13 @@ __device__ __forceinline__ void loss_cell(const float* __restrict__ p, float* __
             const float gy_iou = (gt + gb) * cellf;
             const float gw_iou = (gr - gl) * 0.5f * imgf;
             const float gh_iou = (gb - gt) * 0.5f * imgf;
-            // d/dn of lc*(sqrt(n) - sqrt(g))^2 times sigmoid' = lc*(sw - sg)*sw*(1 - n)
-            g0 = (2.0f * lc * dx + gx_iou) * (bnx * (1.0f - bnx));
-            g1 = (2.0f * lc * dy + gy_iou) * (bny * (1.0f - bny));
-            g2 = lc * dw * sw * (1.0f - bnw) + gw_iou * (bnw * (1.0f - bnw));
-            g3 = lc * dh * sh * (1.0f - bnh) + gh_iou * (bnh * (1.0f - bnh));
+            g0 = (r0 + gx_iou) * (bnx * (1.0f - bnx));
+            g1 = (r1 + gy_iou) * (bny * (1.0f - bny));
+            g2 = r2 + gw_iou * (bnw * (1.0f - bnw));
+            g3 = r3 + gh_iou * (bnh * (1.0f - bnh));
             gc = 2.0f * dc * (conf * (1.0f - conf));
         } else {
-            // no-object term (model.py:270-274)
+            // the other predictors of the cell carry the no-object term (model.py:270-274)
             acc_conf += ln * (conf * conf);
             gc = 2.0f * ln * conf * (conf * (1.0f - conf));
         }
@@ -111,52 +147,27 @@ __device__ __forceinline__ void loss_cell(const float* __restrict__ p, float* __
     }
 
     // class term (model.py:278-294): squared error on the softmax
-    const int c0 = 5 * nb;
-    float* gcl = g + 5 * nb * S2;
-    if (obj) {
-        float m = logit(c0);
+    float m = logit(c0);
 #pragma unroll
-        for (int j = 1; j < nc; ++j) m = fmaxf(m, logit(c0 + j));
-        float s = 0.f;
+    for (int j = 1; j < nc; ++j) m = fmaxf(m, logit(c0 + j));
+    float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < nc; ++j) s += expf(logit(c0 + j) - m);
-        float dot = 0.f, l2 = 0.f;
-        if constexpr (C_CT > 0 && C_CT % 4 == 0) {
-            float gtc[C_CT];
+    for (int j = 0; j < nc; ++j) s += exp_fast(logit(c0 + j) - m);
+    const float rs = rcp_fast(s);
+    float dot = 0.f, l2 = 0.f;
 #pragma unroll
-            for (int j = 0; j < C_CT / 4; ++j) {
-                const float4 v = reinterpret_cast<const float4*>(gcls)[j];
-                gtc[4 * j] = v.x; gtc[4 * j + 1] = v.y; gtc[4 * j + 2] = v.z; gtc[4 * j + 3] = v.w;
-            }
-#pragma unroll
-            for (int j = 0; j < C_CT; ++j) {
-                const float pj = expf(logit(c0 + j) - m) / s;
-                const float d = pj - gtc[j];
-                l2 += d * d;
-                dot += 2.0f * d * pj;
-            }
-#pragma unroll
-            for (int j = 0; j < C_CT; ++j) {
-                const float pj = expf(logit(c0 + j) - m) / s;
-                gcl[j * S2] = pj * (2.0f * (pj - gtc[j]) - dot) * inv_gb;
-            }
-        } else {
-            for (int j = 0; j < nc; ++j) {
-                const float pj = expf(logit(c0 + j) - m) / s;
-                const float d = pj - gcls[j];
-                l2 += d * d;
-                dot += 2.0f * d * pj;
-            }
-            for (int j = 0; j < nc; ++j) {
-                const float pj = expf(logit(c0 + j) - m) / s;
-                gcl[j * S2] = pj * (2.0f * (pj - gcls[j]) - dot) * inv_gb;
-            }
-        }
-        acc_cls += l2;
-    } else {
-#pragma unroll
-        for (int j = 0; j < nc; ++j) gcl[j * S2] = 0.0f;
+    for (int j = 0; j < nc; ++j) {
+        const float pj = exp_fast(logit(c0 + j) - m) * rs;
+        const float d = pj - gtcls(j);
+        l2 += d * d;
+        dot += 2.0f * d * pj;
     }
+#pragma unroll
+    for (int j = 0; j < nc; ++j) {
+        const float pj = exp_fast(logit(c0 + j) - m) * rs;
+        g[(c0 + j) * S2] = pj * (2.0f * (pj - gtcls(j)) - dot) * inv_gb;
+    }
+    acc_cls += l2;
 }
 
 template <int BX_CT, int C_CT>
@@ -207,38 +218,62 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_kernel(
     }
 }
 
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+constexpr int FINALIZE_THREADS = 1024;
+
 // Adds the per-workgroup rows in a fixed order (fp64 accumulation) and writes
-// coord, conf, class, total and total * inv_gb.
-__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ partials,
-                                                            int nrows, float inv_gb,
-                                                            float* __restrict__ loss_terms) {
-    __shared__ double red[256][3];
+// coord, conf, class, total and total * inv_gb.  One row per thread in flight,
+// so the kernel costs one memory round trip; shuffles and one LDS hop reduce.
+__global__ __launch_bounds__(FINALIZE_THREADS) void loss_finalize_kernel(
+    const float* __restrict__ partials, int nrows, float inv_gb, float* __restrict__ loss_terms,
+    float* __restrict__ log_ring, int log_capacity, int* __restrict__ log_cursor) {
+    __shared__ double red[FINALIZE_THREADS / 64][3];
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    for (int r = threadIdx.x; r < nrows; r += 256) {
-        a0 += (double)partials[(size_t)r * 4 + 0];
-        a1 += (double)partials[(size_t)r * 4 + 1];
-        a2 += (double)partials[(size_t)r * 4 + 2];
+    for (int r = threadIdx.x; r < nrows; r += FINALIZE_THREADS) {
+        const float4 v = reinterpret_cast<const float4*>(partials)[r];
+        a0 += (double)v.x;
+        a1 += (double)v.y;
+        a2 += (double)v.z;
     }
-    red[threadIdx.x][0] = a0;
-    red[threadIdx.x][1] = a1;
-    red[threadIdx.x][2] = a2;
+    a0 = wave_sum_f64(a0);
+    a1 = wave_sum_f64(a1);
+    a2 = wave_sum_f64(a2);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        red[wave][0] = a0;
+        red[wave][1] = a1;
+        red[wave][2] = a2;
+    }
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            red[threadIdx.x][0] += red[threadIdx.x + s][0];
-            red[threadIdx.x][1] += red[threadIdx.x + s][1];
-            red[threadIdx.x][2] += red[threadIdx.x + s][2];
-        }
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        const double c = red[0][0], f = red[0][1], k = red[0][2];
+        double c = 0.0, f = 0.0, k = 0.0;
+#pragma unroll
+        for (int w = 0; w < FINALIZE_THREADS / 64; ++w) {
+            c += red[w][0];
+            f += red[w][1];
+            k += red[w][2];
+        }
         const double tot = (c + f) + k;
         loss_terms[0] = (float)c;
         loss_terms[1] = (float)f;
         loss_terms[2] = (float)k;
         loss_terms[3] = (float)tot;
         loss_terms[4] = (float)(tot * (double)inv_gb);
+        if (log_ring) {
+            // device-side loss log: the cursor survives graph replays
+            const int cur = *log_cursor;
+            float* row = log_ring + (size_t)(cur % log_capacity) * 4;
+            row[0] = (float)c;
+            row[1] = (float)f;
+            row[2] = (float)k;
+            row[3] = (float)tot;
+            *log_cursor = cur + 1;
+        }
     }
 }
 

@@ -46,38 +46,72 @@ struct NmsArgs {
 };
 
 // ---- decode primitives shared by every kernel that forms candidates --------------
+// `logit(ch)` returns channel ch of the cell: from registers when the shape is a
+// compile-time one (all channels fetched up front, one memory round trip), from
+// memory otherwise.  The arithmetic is the same either way, so every kernel
+// that decodes a cell produces the same bits.
+
+// reads the cell's channels from the head tensor on use
+struct MemLogits {
+    const float* __restrict__ p;
+    int S2;
+    __device__ __forceinline__ float operator()(int ch) const { return p[ch * S2]; }
+};
+
 // class of a cell: argmax of the class logits, first index on ties
-__device__ __forceinline__ int cell_class(const float* __restrict__ p, int c0, int nc, int S2) {
+template <class L>
+__device__ __forceinline__ int cell_class(const L& logit, int c0, int nc) {
     int best = 0;
-    float m = p[c0 * S2];
+    float m = logit(c0);
+#pragma unroll
     for (int j = 1; j < nc; ++j) {
-        const float v = p[(c0 + j) * S2];
+        const float v = logit(c0 + j);
         if (v > m) { m = v; best = j; }
     }
     return best;
 }
 
-// predictor with the higher confidence, first index on ties (torch.max, model.py:387)
-__device__ __forceinline__ int cell_best_conf(const float* __restrict__ p, int nb, int S2,
-                                              float& conf_best) {
+// run-time class count: the logits are fetched eight at a time so that one cell
+// costs nc/8 memory round trips instead of nc
+__device__ __forceinline__ int cell_class_mem(const float* __restrict__ p, int c0, int nc, int S2) {
     int best = 0;
-    conf_best = sigmoidf_(p[4 * S2]);
+    float m = p[c0 * S2];
+    for (int j0 = 1; j0 < nc; j0 += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = (j0 + u < nc) ? p[(c0 + j0 + u) * S2] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j0 + u < nc && t[u] > m) { m = t[u]; best = j0 + u; }
+    }
+    return best;
+}
+
+// predictor with the higher confidence, first index on ties (torch.max, model.py:387)
+template <class L>
+__device__ __forceinline__ int cell_best_conf(const L& logit, int nb, float& conf_best) {
+    int best = 0;
+    conf_best = sigmoidf_(logit(4));
+#pragma unroll
     for (int k = 1; k < nb; ++k) {
-        const float c = sigmoidf_(p[(5 * k + 4) * S2]);
+        const float c = sigmoidf_(logit(5 * k + 4));
         if (c > conf_best) { conf_best = c; best = k; }
     }
     return best;
 }
 
-// box of predictor k of a cell in pixels (model.py:185-188)
-__device__ __forceinline__ Box cell_box(const float* __restrict__ p, int k, int cell, int S,
-                                        int S2, float cellf, float imgf) {
-    const float nx = sigmoidf_(p[(5 * k + 0) * S2]);
-    const float ny = sigmoidf_(p[(5 * k + 1) * S2]);
-    const float nw = sigmoidf_(p[(5 * k + 2) * S2]);
-    const float nh = sigmoidf_(p[(5 * k + 3) * S2]);
-    return decode_box(nx, ny, nw, nh, cellf * (float)(cell / S), cellf * (float)(cell % S),
-                      cellf, imgf);
+// box of the predictor whose x,y,w,h logits are given, in pixels (model.py:185-188)
+__device__ __forceinline__ Box box_from_logits(float lx, float ly, float lw, float lh, int cell,
+                                               int S, float cellf, float imgf) {
+    return decode_box(sigmoidf_(lx), sigmoidf_(ly), sigmoidf_(lw), sigmoidf_(lh),
+                      cellf * (float)(cell / S), cellf * (float)(cell % S), cellf, imgf);
+}
+
+template <class L>
+__device__ __forceinline__ Box cell_box(const L& logit, int k, int cell, int S, float cellf,
+                                        float imgf) {
+    return box_from_logits(logit(5 * k + 0), logit(5 * k + 1), logit(5 * k + 2), logit(5 * k + 3),
+                           cell, S, cellf, imgf);
 }
 
 template <int NT>
@@ -92,7 +126,9 @@ __device__ __forceinline__ void group_sync() {
     }
 }
 
-template <int NT, int ITEMS, int SRC>
+// SRC 0: candidates decoded from the head tensor (BX_CT, C_CT > 0: compile-time
+// predictor/class counts, 0: run-time); SRC 1: candidates loaded from memory.
+template <int NT, int ITEMS, int SRC, int BX_CT, int C_CT>
 __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int IPB = NMS_BLOCK / NT;  // images per workgroup
@@ -133,38 +169,74 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
     if (t == 0) { misc[0] = 0; misc[1] = 0; }
 
     if constexpr (SRC == 0) {
-        const long long D = 5 * a.nb + a.nc;
-        const float* pimg = a.pred + (live_img ? img : 0) * D * S2;
+        constexpr bool kStatic = BX_CT > 0 && C_CT > 0;
+        // all channels of a cell in registers only while that stays cheap
+        constexpr bool kStaticCell = kStatic && (5 * BX_CT + C_CT <= 48);
+        const int nb = kStatic ? BX_CT : a.nb;
+        const int nc = kStatic ? C_CT : a.nc;
+        const long long D = 5 * nb + nc;
+        const float* pimg = a.pred + img * D * S2;
         if (a.mode == 0) {
             // slot = cell; the higher-confidence predictor is the candidate
 #pragma unroll
             for (int e = 0; e < ITEMS; ++e) {
                 const int cell = e * NT + t;
-                if (cell < nslot && live_img) {
+                if (cell < nslot) {
                     const float* p = pimg + cell;
                     float cb;
-                    const int k = cell_best_conf(p, a.nb, S2, cb);
-                    cbox[e] = cell_box(p, k, cell, a.S, S2, a.cellf, a.imgf);
+                    int k;
+                    if constexpr (kStaticCell) {
+                        // every channel of the cell in flight at once
+                        float v[5 * BX_CT + C_CT];
+#pragma unroll
+                        for (int ch = 0; ch < 5 * BX_CT + C_CT; ++ch) v[ch] = p[ch * S2];
+                        auto logit = [&](int ch) -> float { return v[ch]; };
+                        k = cell_best_conf(logit, BX_CT, cb);
+                        float lx = v[0], ly = v[1], lw = v[2], lh = v[3];
+#pragma unroll
+                        for (int q = 1; q < BX_CT; ++q)
+                            if (k == q) { lx = v[5 * q]; ly = v[5 * q + 1]; lw = v[5 * q + 2]; lh = v[5 * q + 3]; }
+                        cbox[e] = box_from_logits(lx, ly, lw, lh, cell, a.S, a.cellf, a.imgf);
+                        ccl[e] = cell_class(logit, 5 * BX_CT, C_CT);
+                    } else {
+                        const MemLogits logit{p, S2};
+                        k = cell_best_conf(logit, nb, cb);
+                        cbox[e] = cell_box(logit, k, cell, a.S, a.cellf, a.imgf);
+                        ccl[e] = cell_class_mem(p, 5 * nb, nc, S2);
+                    }
                     cscore[e] = cb;
-                    ccl[e] = cell_class(p, 5 * a.nb, a.nc, S2);
-                    cidx[e] = cell * a.nb + k;
+                    cidx[e] = cell * nb + k;
                     cvalid[e] = cb >= a.conf_thr;
                 }
             }
         } else {
             // slot = cell*nb + k; the class is computed once per cell
-            for (int cell = t; cell < S2; cell += NT)
-                ccls[cell] = live_img ? cell_class(pimg + cell, 5 * a.nb, a.nc, S2) : 0;
+#pragma unroll
+            for (int e = 0; e < ITEMS; ++e) {   // S*S <= nslot <= NT*ITEMS
+                const int cell = e * NT + t;
+                if (cell >= S2) continue;
+                const float* p = pimg + cell;
+                if constexpr (kStatic) {
+                    float v[C_CT];
+#pragma unroll
+                    for (int j = 0; j < C_CT; ++j) v[j] = p[(5 * BX_CT + j) * S2];
+                    auto logit = [&](int ch) -> float { return v[ch]; };
+                    ccls[cell] = cell_class(logit, 0, C_CT);
+                } else {
+                    ccls[cell] = cell_class_mem(p, 5 * nb, nc, S2);
+                }
+            }
             group_sync<NT>();
 #pragma unroll
             for (int e = 0; e < ITEMS; ++e) {
                 const int n = e * NT + t;
-                if (n < nslot && live_img) {
-                    const int cell = n / a.nb;
-                    const int k = n - cell * a.nb;
-                    const float* p = pimg + cell;
-                    cbox[e] = cell_box(p, k, cell, a.S, S2, a.cellf, a.imgf);
-                    cscore[e] = sigmoidf_(p[(5 * k + 4) * S2]);
+                if (n < nslot) {
+                    const int cell = n / nb;
+                    const int k = n - cell * nb;
+                    const float* p = pimg + cell + (5 * k) * S2;
+                    const float lx = p[0], ly = p[S2], lw = p[2 * S2], lh = p[3 * S2], lc = p[4 * S2];
+                    cbox[e] = box_from_logits(lx, ly, lw, lh, cell, a.S, a.cellf, a.imgf);
+                    cscore[e] = sigmoidf_(lc);
                     ccl[e] = ccls[cell];
                     cidx[e] = n;
                     cvalid[e] = cscore[e] >= a.conf_thr;
@@ -319,14 +391,15 @@ __global__ __launch_bounds__(256) void decode_candidates_kernel(
         const long long img = g / S2;
         const int cell = (int)(g - img * S2);
         const float* p = pred + img * D * S2 + cell;
-        const int cls = cell_class(p, 5 * nb, nc, S2);
+        const MemLogits logit{p, S2};
+        const int cls = cell_class_mem(p, 5 * nb, nc, S2);
         float cb;
-        const int best = cell_best_conf(p, nb, S2, cb);
+        const int best = cell_best_conf(logit, nb, cb);
         for (int k = 0; k < nb; ++k) {
             const long long o = g * nb + k;
-            const Box b = cell_box(p, k, cell, S, S2, cellf, imgf);
+            const Box b = cell_box(logit, k, cell, S, cellf, imgf);
             reinterpret_cast<float4*>(c_ltrb)[o] = make_float4(b.l, b.t, b.r, b.b);
-            c_score[o] = sigmoidf_(p[(5 * k + 4) * S2]);
+            c_score[o] = sigmoidf_(logit(5 * k + 4));
             c_cls[o] = cls;
             c_present[o] = (mode == 1 || k == best) ? 1 : 0;
         }

@@ -63,19 +63,17 @@ void nms_layout(yh::NmsArgs& a, int slot_pad) {
     a.region_bytes = off;
 }
 
-template <int SRC>
-int launch_nms(yh::NmsArgs a, hipStream_t st) {
-    if (a.batch == 0) return YH_OK;
-    if (a.nslot > YH_MAX_CANDIDATES || a.nout > YH_MAX_CANDIDATES) return YH_ERR_UNSUPPORTED;
-#define YH_NMS_CASE(NT, ITEMS)                                                            \
-    {                                                                                     \
-        nms_layout(a, NT * ITEMS);                                                        \
-        const int ipb = yh::NMS_BLOCK / NT;                                               \
-        const unsigned grid = (unsigned)((a.batch + ipb - 1) / ipb);                      \
-        const size_t lds = (size_t)a.region_bytes * ipb;                                  \
-        hipLaunchKernelGGL((yh::nms_kernel<NT, ITEMS, SRC>), dim3(grid), dim3(yh::NMS_BLOCK), \
-                           lds, st, a);                                                   \
-        return launch_status();                                                           \
+template <int SRC, int BX_CT, int C_CT>
+int launch_nms_shape(yh::NmsArgs a, hipStream_t st) {
+#define YH_NMS_CASE(NT, ITEMS)                                                              \
+    {                                                                                       \
+        nms_layout(a, NT * ITEMS);                                                          \
+        const int ipb = yh::NMS_BLOCK / NT;                                                 \
+        const unsigned grid = (unsigned)((a.batch + ipb - 1) / ipb);                        \
+        const size_t lds = (size_t)a.region_bytes * ipb;                                    \
+        hipLaunchKernelGGL((yh::nms_kernel<NT, ITEMS, SRC, BX_CT, C_CT>), dim3(grid),       \
+                           dim3(yh::NMS_BLOCK), lds, st, a);                                \
+        return launch_status();                                                             \
     }
     if (a.nslot <= 64) YH_NMS_CASE(64, 1)
     if (a.nslot <= 128) YH_NMS_CASE(64, 2)
@@ -83,6 +81,18 @@ int launch_nms(yh::NmsArgs a, hipStream_t st) {
     if (a.nslot <= 512) YH_NMS_CASE(256, 2)
     YH_NMS_CASE(256, 4)
 #undef YH_NMS_CASE
+}
+
+template <int SRC>
+int launch_nms(const yh::NmsArgs& a, hipStream_t st) {
+    if (a.batch == 0) return YH_OK;
+    if (a.nslot > YH_MAX_CANDIDATES || a.nout > YH_MAX_CANDIDATES) return YH_ERR_UNSUPPORTED;
+    if constexpr (SRC == 0) {
+        // the two shapes the head is benchmarked on get compile-time channel counts
+        if (a.nb == 2 && a.nc == 20) return launch_nms_shape<0, 2, 20>(a, st);
+        if (a.nb == 5 && a.nc == 80) return launch_nms_shape<0, 5, 80>(a, st);
+    }
+    return launch_nms_shape<SRC, 0, 0>(a, st);
 }
 
 }  // namespace
@@ -115,44 +125,76 @@ size_t yh_workspace_bytes(int op, int64_t batch, int S, int Bx, int C) {
     return (size_t)(rows < 1 ? 1 : rows) * 4 * sizeof(float);
 }
 
-int yh_loss_fwd_bwd(const float* pred, const float* gt_xywh, const float* gt_cls,
-                    const uint8_t* obj_mask, float* grad_pred, float* loss_terms,
-                    void* workspace, size_t workspace_bytes, int64_t batch, int S, int Bx,
-                    int C, int img_size, float lambda_coord, float lambda_noobj,
-                    float inv_global_batch, void* stream) {
+int yh_loss_partials(const float* pred, const float* gt_xywh, const float* gt_cls,
+                     const uint8_t* obj_mask, float* grad_pred, void* workspace,
+                     size_t workspace_bytes, int64_t batch, int S, int Bx, int C, int img_size,
+                     float lambda_coord, float lambda_noobj, float inv_global_batch,
+                     void* stream) {
     if (const int rc = check_shape(batch, S, Bx, C, img_size)) return rc;
-    if (!loss_terms || !workspace) return !workspace ? YH_ERR_WORKSPACE : YH_ERR_NULL;
+    if (!workspace) return YH_ERR_WORKSPACE;
     if (batch > 0 && (!pred || !gt_xywh || !gt_cls || !obj_mask || !grad_pred)) return YH_ERR_NULL;
     if (workspace_bytes < yh_workspace_bytes(YH_OP_LOSS, batch, S, Bx, C)) return YH_ERR_WORKSPACE;
     if (!aligned(workspace, 16) || !aligned(gt_xywh, 16) || !aligned(pred, 4) ||
-        !aligned(grad_pred, 4) || !aligned(gt_cls, 4) || !aligned(loss_terms, 4))
+        !aligned(grad_pred, 4) || !aligned(gt_cls, 4))
         return YH_ERR_ALIGN;
     if (isnan(lambda_coord) || isnan(lambda_noobj) || isnan(inv_global_batch)) return YH_ERR_ARG;
 
     hipStream_t st = (hipStream_t)stream;
     float* partials = (float*)workspace;
     const int64_t rows = loss_blocks(batch, S);
+    if (rows == 0) return YH_OK;
     const int g = loss_imgs_per_block(S);
     const float cellf = (float)(img_size / S);
     const float imgf = (float)img_size;
-    if (rows > 0) {
-        const bool fast = Bx == 2 && C == 20 && aligned(gt_cls, 16);
-        if (fast) {
-            hipLaunchKernelGGL((yh::loss_fwd_bwd_kernel<2, 20>), dim3((unsigned)rows),
-                               dim3(yh::LOSS_THREADS), 0, st, pred, gt_xywh, gt_cls, obj_mask,
-                               grad_pred, partials, (long long)batch, S, Bx, C, g, cellf, imgf,
-                               lambda_coord, lambda_noobj, inv_global_batch);
-        } else {
-            hipLaunchKernelGGL((yh::loss_fwd_bwd_kernel<0, 0>), dim3((unsigned)rows),
-                               dim3(yh::LOSS_THREADS), 0, st, pred, gt_xywh, gt_cls, obj_mask,
-                               grad_pred, partials, (long long)batch, S, Bx, C, g, cellf, imgf,
-                               lambda_coord, lambda_noobj, inv_global_batch);
-        }
-        if (const int rc = launch_status()) return rc;
+    const bool fast = Bx == 2 && C == 20 && aligned(gt_cls, 16);
+    if (fast) {
+        hipLaunchKernelGGL((yh::loss_fwd_bwd_kernel<2, 20>), dim3((unsigned)rows),
+                           dim3(yh::LOSS_THREADS), 0, st, pred, gt_xywh, gt_cls, obj_mask,
+                           grad_pred, partials, (long long)batch, S, Bx, C, g, cellf, imgf,
+                           lambda_coord, lambda_noobj, inv_global_batch);
+    } else {
+        hipLaunchKernelGGL((yh::loss_fwd_bwd_kernel<0, 0>), dim3((unsigned)rows),
+                           dim3(yh::LOSS_THREADS), 0, st, pred, gt_xywh, gt_cls, obj_mask,
+                           grad_pred, partials, (long long)batch, S, Bx, C, g, cellf, imgf,
+                           lambda_coord, lambda_noobj, inv_global_batch);
     }
-    hipLaunchKernelGGL(yh::loss_finalize_kernel, dim3(1), dim3(256), 0, st, partials, (int)rows,
-                       inv_global_batch, loss_terms);
     return launch_status();
+}
+
+int yh_loss_finalize(const void* workspace, size_t workspace_bytes, int64_t batch, int S,
+                     float inv_global_batch, float* loss_terms, float* log_ring,
+                     int log_capacity, int32_t* log_cursor, void* stream) {
+    if (batch < 0 || S < 1 || S > YH_MAX_S) return YH_ERR_SHAPE;
+    if (!loss_terms) return YH_ERR_NULL;
+    if (!workspace || workspace_bytes < yh_workspace_bytes(YH_OP_LOSS, batch, S, 1, 1))
+        return YH_ERR_WORKSPACE;
+    if (log_ring && (!log_cursor || log_capacity < 1)) return YH_ERR_ARG;
+    if (!aligned(workspace, 16) || !aligned(loss_terms, 4) || !aligned(log_ring, 4) ||
+        !aligned(log_cursor, 4))
+        return YH_ERR_ALIGN;
+    if (isnan(inv_global_batch)) return YH_ERR_ARG;
+    hipLaunchKernelGGL(yh::loss_finalize_kernel, dim3(1), dim3(yh::FINALIZE_THREADS), 0,
+                       (hipStream_t)stream,
+                       (const float*)workspace, (int)loss_blocks(batch, S), inv_global_batch,
+                       loss_terms, log_ring, log_capacity, (int*)log_cursor);
+    return launch_status();
+}
+
+int yh_loss_fwd_bwd(const float* pred, const float* gt_xywh, const float* gt_cls,
+                    const uint8_t* obj_mask, float* grad_pred, float* loss_terms,
+                    void* workspace, size_t workspace_bytes, int64_t batch, int S, int Bx,
+                    int C, int img_size, float lambda_coord, float lambda_noobj,
+                    float inv_global_batch, void* stream) {
+    if (!loss_terms) {
+        const int rc = check_shape(batch, S, Bx, C, img_size);
+        return rc ? rc : YH_ERR_NULL;
+    }
+    if (const int rc = yh_loss_partials(pred, gt_xywh, gt_cls, obj_mask, grad_pred, workspace,
+                                        workspace_bytes, batch, S, Bx, C, img_size, lambda_coord,
+                                        lambda_noobj, inv_global_batch, stream))
+        return rc;
+    return yh_loss_finalize(workspace, workspace_bytes, batch, S, inv_global_batch, loss_terms,
+                            nullptr, 0, nullptr, stream);
 }
 
 int yh_scale_grad(float* grad, const float* scale, int64_t n, void* stream) {

@@ -47,6 +47,24 @@ def _need(t: torch.Tensor, name: str, dtype, shape=None) -> torch.Tensor:
     return t
 
 
+class LossLog:
+    """Device-side ring of the per-step loss sums (coord, conf, class, total).
+
+    ``yh_loss_finalize`` appends one row per step and advances a cursor that lives
+    on the device, so a captured HIP graph logs every replay without host work.
+    Nothing on the training critical path reads the ring; a data-parallel job
+    reduces it across ranks every ``capacity`` steps at most (yolo_amd.dist)."""
+
+    def __init__(self, device, capacity: int = 64):
+        self.capacity = int(capacity)
+        self.ring = torch.zeros(self.capacity, 4, dtype=torch.float32, device=device)
+        self.cursor = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def reset(self):
+        self.ring.zero_()
+        self.cursor.zero_()
+
+
 class _LossFunction(torch.autograd.Function):
     """Forward launches the fused forward+backward kernel and keeps the
     gradient; backward hands it out, multiplied on the device by the incoming
@@ -132,7 +150,7 @@ class YOLOv1Head(nn.Module):
         return ws
 
     # --------------------------------------------------------------------- loss
-    def _launch_loss(self, out, gt_norm_xywh, gt_cls_prob, obj_mask, inv_global_batch):
+    def _launch_loss(self, out, gt_norm_xywh, gt_cls_prob, obj_mask, inv_global_batch, log=None):
         out = self._check_out(out)
         bsz, n = out.shape[0], self.n_grid
         _need(gt_norm_xywh, "gt_norm_xywh", torch.float32, (bsz, n, 1, 4))
@@ -150,22 +168,31 @@ class YOLOv1Head(nn.Module):
         ws = self._get_workspace(out.device, nbytes)
         grad = torch.empty_like(out)
         terms = torch.empty(5, dtype=torch.float32, device=out.device)
+        if log is not None and log.ring.device != out.device:
+            raise ValueError(f"loss log on {log.ring.device}, out is on {out.device}")
         with torch.cuda.device(out.device):
-            _lib.check(lib.yh_loss_fwd_bwd(
+            st = _stream(out.device)
+            _lib.check(lib.yh_loss_partials(
                 out.data_ptr(), gt_norm_xywh.data_ptr(), gt_cls_prob.data_ptr(),
-                obj_mask.data_ptr(), grad.data_ptr(), terms.data_ptr(), ws.data_ptr(),
-                ws.numel(), bsz, self.n_cells, self.n_bboxes, self.n_classes, self.img_size,
-                self.coord_coeff, self.noobj_coeff, float(inv_global_batch),
-                _stream(out.device)))
+                obj_mask.data_ptr(), grad.data_ptr(), ws.data_ptr(), ws.numel(), bsz,
+                self.n_cells, self.n_bboxes, self.n_classes, self.img_size, self.coord_coeff,
+                self.noobj_coeff, float(inv_global_batch), st))
+            _lib.check(lib.yh_loss_finalize(
+                ws.data_ptr(), ws.numel(), bsz, self.n_cells, float(inv_global_batch),
+                terms.data_ptr(), None if log is None else log.ring.data_ptr(),
+                0 if log is None else log.capacity,
+                None if log is None else log.cursor.data_ptr(), st))
         return terms, grad
 
-    def loss_fwd_bwd(self, out, gt_norm_xywh, gt_cls_prob, obj_mask, global_batch=None):
+    def loss_fwd_bwd(self, out, gt_norm_xywh, gt_cls_prob, obj_mask, global_batch=None,
+                     log: Optional[LossLog] = None):
         """Functional form: one kernel pass returning ``(terms, grad)`` with
         terms = [coord_sum, conf_sum, cls_sum, total_sum, total/global_batch] and
-        grad = d(total/global_batch)/d(out).  No autograd graph is recorded."""
+        grad = d(total/global_batch)/d(out).  No autograd graph is recorded.
+        ``log`` receives the four sums as one more row (see LossLog)."""
         gb = out.shape[0] if global_batch is None else int(global_batch)
         return self._launch_loss(out.detach(), gt_norm_xywh, gt_cls_prob, obj_mask,
-                                 1.0 / max(gb, 1))
+                                 1.0 / max(gb, 1), log)
 
     def get_loss(self, image, gt_norm_xywh, gt_cls_prob, obj_mask, global_batch=None):
         """model.py:296-317: (coord + conf + cls) / B as a 0-d tensor that supports
