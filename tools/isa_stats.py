@@ -4,7 +4,7 @@ from collections import Counter
 path = glob.glob("build/asm/*gfx950.s")[0]
 s = open(path).read()
 # kernels start at a label "<mangled>:" and end at s_endpgm
-for m in re.finditer(r'^(_ZN2yh\S*):[^\n]*\n(.*?)s_endpgm', s, re.S | re.M):
+for m in re.finditer(r'^(_ZN2yh\S*):[^\n]*\n(.*?)\.Lfunc_end', s, re.S | re.M):
     name = m.group(1)
     body = m.group(2)
     if len(sys.argv) > 1 and sys.argv[1] not in name:

@@ -15,7 +15,8 @@
 //      LDS rebuilt with one ballot per wavefront per step, so a pivot's bit is
 //      final before it is used.  The step count is the longest segment - 1.
 //   E  kept rows get their output slot from a prefix popcount over the
-//      liveness words, are staged in LDS and leave with coalesced stores.
+//      liveness words and are stored straight from registers (consecutive
+//      survivors write consecutive 24-byte rows); the tail is zero-filled.
 #pragma once
 #include "head_math.hpp"
 
@@ -41,8 +42,9 @@ struct NmsArgs {
     int nout;   // rows of dets per image
     float cellf, imgf, conf_thr, iou_thr;
     // per-image LDS region: byte offsets of the arrays inside it, and its size
-    int off_keys, off_box, off_meta, off_alive, off_misc, off_stage, off_kidx, off_ccls;
+    int off_keys, off_box, off_meta, off_alive, off_misc, off_ccls;
     int region_bytes;
+    int dbg_stop;  // profiling aid: leave after this phase (0 = run everything)
 };
 
 // ---- decode primitives shared by every kernel that forms candidates --------------
@@ -149,8 +151,6 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
     int4* smeta = reinterpret_cast<int4*>(region + a.off_meta);
     unsigned long long* alive = reinterpret_cast<unsigned long long*>(region + a.off_alive);
     int* misc = reinterpret_cast<int*>(region + a.off_misc);  // [0] valid count, [1] max pos
-    float* stage = reinterpret_cast<float*>(region + a.off_stage);
-    int* kidx = reinterpret_cast<int*>(region + a.off_kidx);
     int* ccls = reinterpret_cast<int*>(region + a.off_ccls);
 
     const int nslot = a.nslot;
@@ -260,6 +260,7 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
         }
     }
 
+    if (a.dbg_stop == 1) { if (cvalid[0] && cscore[0] == 12345.f) a.keep_count[img] = ccl[0] + (int)cbox[0].l; return; }
     // ---- phase B: keys, rank, segment start ---------------------------------------
     unsigned long long key[ITEMS], clsbase[ITEMS];
 #pragma unroll
@@ -275,8 +276,11 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
     int rank[ITEMS], seg[ITEMS];
 #pragma unroll
     for (int e = 0; e < ITEMS; ++e) { rank[e] = 0; seg[e] = 0; }
+    // every lane reads the same LDS address per iteration (a broadcast); unrolled so
+    // that several reads are in flight
+#pragma unroll 8
     for (int j = 0; j < nslot; ++j) {
-        const unsigned long long kj = keys[j];  // same address in every lane: broadcast
+        const unsigned long long kj = keys[j];
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
             rank[e] += kj < key[e] ? 1 : 0;
@@ -284,6 +288,7 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
         }
     }
 
+    if (a.dbg_stop == 2) { if (rank[0] == 12345) a.keep_count[img] = seg[0]; return; }
     // ---- phase C: scatter to rank order ---------------------------------------------
     int nv_local = 0, mp_local = 0;
 #pragma unroll
@@ -304,6 +309,7 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
     const int nvalid = misc[0];
     const int maxpos = misc[1];
 
+    if (a.dbg_stop == 3) return;
     // ---- phase D: greedy suppression over sorted positions ----------------------------
     Box mybox[ITEMS];
     int4 mymeta[ITEMS];
@@ -319,63 +325,98 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
             mybox[e] = {b.x, b.y, b.z, b.w};
             mymeta[e] = smeta[i];
         }
-        const unsigned long long w = __ballot(al[e]);
-        if (lane == 0) alive[e * NW + wv] = w;
     }
-    group_sync<NT>();
-    for (int step = 0; step < maxpos; ++step) {
+    int pos_out[ITEMS];   // output row of a survivor
+    int total = 0;        // survivors of the image
+    if constexpr (NT == 64) {
+        // the liveness words of the image are wave-uniform: keep them in scalar registers
+        unsigned long long aw[ITEMS];
 #pragma unroll
-        for (int e = 0; e < ITEMS; ++e) {
-            const int i = e * NT + t;
-            if (al[e] && i - mymeta[e].w > step) {
-                const int pv = mymeta[e].w + step;  // pivot: step-th member of my class segment
-                if ((alive[pv >> 6] >> (pv & 63)) & 1ull) {
-                    const float4 b = sbox[pv];
-                    const Box pb = {b.x, b.y, b.z, b.w};
-                    if (iou_pair(pb, mybox[e]) > a.iou_thr) al[e] = false;
+        for (int e = 0; e < ITEMS; ++e) aw[e] = __ballot(al[e]);
+        for (int step = 0; step < maxpos; ++step) {
+#pragma unroll
+            for (int e = 0; e < ITEMS; ++e) {
+                const int i = e * NT + t;
+                if (al[e] && i - mymeta[e].w > step) {
+                    const int pv = mymeta[e].w + step;  // pivot: step-th member of my class segment
+                    unsigned long long w = aw[0];
+#pragma unroll
+                    for (int q = 1; q < ITEMS; ++q) w = (pv >> 6) == q ? aw[q] : w;
+                    if ((w >> (pv & 63)) & 1ull) {
+                        const float4 b = sbox[pv];
+                        const Box pb = {b.x, b.y, b.z, b.w};
+                        if (iou_pair(pb, mybox[e]) > a.iou_thr) al[e] = false;
+                    }
                 }
             }
+#pragma unroll
+            for (int e = 0; e < ITEMS; ++e) aw[e] = __ballot(al[e]);
         }
-        group_sync<NT>();  // every read of the liveness words precedes their update
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            pos_out[e] = total + __popcll(aw[e] & ((1ull << lane) - 1ull));
+            total += __popcll(aw[e]);
+        }
+    } else {
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
             const unsigned long long w = __ballot(al[e]);
             if (lane == 0) alive[e * NW + wv] = w;
         }
         group_sync<NT>();
-    }
-
-    // ---- phase E: compact the survivors, stage, store -----------------------------------
-    const int nout = a.nout;
-    for (int i = t; i < nout * 6; i += NT) stage[i] = 0.0f;
-    for (int i = t; i < nout; i += NT) kidx[i] = -1;
-    group_sync<NT>();
-    int total = 0;
+        for (int step = 0; step < maxpos; ++step) {
 #pragma unroll
-    for (int w = 0; w < ITEMS * NW; ++w) total += __popcll(alive[w]);
+            for (int e = 0; e < ITEMS; ++e) {
+                const int i = e * NT + t;
+                if (al[e] && i - mymeta[e].w > step) {
+                    const int pv = mymeta[e].w + step;
+                    if ((alive[pv >> 6] >> (pv & 63)) & 1ull) {
+                        const float4 b = sbox[pv];
+                        const Box pb = {b.x, b.y, b.z, b.w};
+                        if (iou_pair(pb, mybox[e]) > a.iou_thr) al[e] = false;
+                    }
+                }
+            }
+            group_sync<NT>();  // every read of the liveness words precedes their update
 #pragma unroll
-    for (int e = 0; e < ITEMS; ++e) {
-        if (al[e]) {
+            for (int e = 0; e < ITEMS; ++e) {
+                const unsigned long long w = __ballot(al[e]);
+                if (lane == 0) alive[e * NW + wv] = w;
+            }
+            group_sync<NT>();
+        }
+#pragma unroll
+        for (int w = 0; w < ITEMS * NW; ++w) total += __popcll(alive[w]);
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
             const int myw = e * NW + wv;
             int pos = __popcll(alive[myw] & ((1ull << lane) - 1ull));
             for (int w = 0; w < myw; ++w) pos += __popcll(alive[w]);
-            float* row = stage + pos * 6;
-            row[0] = mybox[e].l; row[1] = mybox[e].t; row[2] = mybox[e].r; row[3] = mybox[e].b;
-            row[4] = __int_as_float(mymeta[e].x);
-            row[5] = (float)mymeta[e].y;
-            kidx[pos] = mymeta[e].z;
+            pos_out[e] = pos;
         }
     }
-    group_sync<NT>();
-    if (live_img) {
-        float* dst = a.dets + img * (long long)nout * 6;
-        for (int i = t; i < nout * 6; i += NT) dst[i] = stage[i];
-        if (a.keep_idx) {
-            int32_t* kd = a.keep_idx + img * (long long)nout;
-            for (int i = t; i < nout; i += NT) kd[i] = kidx[i];
+    if (a.dbg_stop == 4) { if (al[0] && mybox[0].l == 12345.f) a.keep_count[img] = 1; return; }
+
+    // ---- phase E: survivors go straight to their output rows; the rest is zero-filled ----
+    // A row is 24 bytes, so 8-byte stores are always aligned; consecutive survivors
+    // write consecutive rows.
+    const int nout = a.nout;
+    float2* dst2 = reinterpret_cast<float2*>(a.dets + img * (long long)nout * 6);
+    int32_t* kd = a.keep_idx ? a.keep_idx + img * (long long)nout : nullptr;
+#pragma unroll
+    for (int e = 0; e < ITEMS; ++e) {
+        if (al[e]) {
+            float2* row = dst2 + pos_out[e] * 3;
+            row[0] = make_float2(mybox[e].l, mybox[e].t);
+            row[1] = make_float2(mybox[e].r, mybox[e].b);
+            row[2] = make_float2(__int_as_float(mymeta[e].x), (float)mymeta[e].y);
+            if (kd) kd[pos_out[e]] = mymeta[e].z;
         }
-        if (t == 0) a.keep_count[img] = total;
     }
+    for (int i = total * 3 + t; i < nout * 3; i += NT) dst2[i] = make_float2(0.0f, 0.0f);
+    if (kd)
+        for (int i = total + t; i < nout; i += NT) kd[i] = -1;
+    if (t == 0) a.keep_count[img] = total;
 }
 
 // ---- candidates to global memory (the values nms_kernel<.,.,0> forms in registers) ---

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/yolo_head.h"
 #include "decode_kernels.hpp"
@@ -45,15 +46,10 @@ inline int round16(int x) { return (x + 15) & ~15; }
 
 // LDS layout of one image's region in nms_kernel
 void nms_layout(yh::NmsArgs& a, int slot_pad) {
-    const int sort_bytes = slot_pad * (8 + 16 + 16);
-    const int out_bytes = round16(a.nout * 24) + round16(a.nout * 4);
     a.off_keys = 0;
     a.off_box = slot_pad * 8;
     a.off_meta = slot_pad * 24;
-    // the output staging reuses the sort arrays: they are dead once suppression ends
-    a.off_stage = 0;
-    a.off_kidx = round16(a.nout * 24);
-    int off = sort_bytes > out_bytes ? sort_bytes : out_bytes;
+    int off = slot_pad * (8 + 16 + 16);
     a.off_alive = off;
     off += round16((slot_pad / 64) * 8);
     a.off_misc = off;
@@ -259,7 +255,7 @@ int yh_decode_nms(const float* pred, float* dets, int32_t* keep_count, int32_t* 
     if ((int64_t)S * S * Bx > YH_MAX_CANDIDATES) return YH_ERR_UNSUPPORTED;
     if (batch == 0) return YH_OK;
     if (!pred || !dets || !keep_count) return YH_ERR_NULL;
-    if (!aligned(pred, 4) || !aligned(dets, 4) || !aligned(keep_count, 4) || !aligned(keep_idx, 4))
+    if (!aligned(pred, 4) || !aligned(dets, 8) || !aligned(keep_count, 4) || !aligned(keep_idx, 4))
         return YH_ERR_ALIGN;
     yh::NmsArgs a = {};
     a.pred = pred;
@@ -274,6 +270,7 @@ int yh_decode_nms(const float* pred, float* dets, int32_t* keep_count, int32_t* 
     a.imgf = (float)img_size;
     a.conf_thr = conf_thresh;
     a.iou_thr = iou_thresh;
+    { const char* e = getenv("YH_NMS_STOP"); a.dbg_stop = e ? atoi(e) : 0; }
     return launch_nms<0>(a, (hipStream_t)stream);
 }
 
@@ -286,7 +283,7 @@ int yh_nms(const float* cand_ltrb, const float* cand_score, const int32_t* cand_
     if (batch == 0) return YH_OK;
     if (!cand_ltrb || !cand_score || !cand_cls || !dets || !keep_count) return YH_ERR_NULL;
     if (!aligned(cand_ltrb, 16) || !aligned(cand_score, 4) || !aligned(cand_cls, 4) ||
-        !aligned(dets, 4) || !aligned(keep_count, 4) || !aligned(keep_idx, 4))
+        !aligned(dets, 8) || !aligned(keep_count, 4) || !aligned(keep_idx, 4))
         return YH_ERR_ALIGN;
     yh::NmsArgs a = {};
     a.c_ltrb = cand_ltrb;
