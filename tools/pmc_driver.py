@@ -1,0 +1,32 @@
+"""Driver for the rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs).
+
+Launch order: two calibration copies with known byte counts -- a 16-byte-per-lane
+copy and a 4-byte-per-lane copy (source offset by one float so PyTorch's copy
+kernel cannot vectorise) -- then the loss kernel and the decode+NMS kernel of the
+benchmark workload (batch 4096), three launches each."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from yolo_amd import YOLOv1Head, synth, MODE_REFERENCE, _lib
+dev = torch.device("cuda:0")
+B = 4096
+head = YOLOv1Head()
+pred, gx, gc, om = (t.to(dev) for t in synth.make_inputs(B))
+lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
+ws = head._get_workspace(dev, lib.yh_workspace_bytes(0, B, 7, 2, 20))
+grad = torch.empty_like(pred); om8 = om.view(torch.uint8)
+dets = torch.empty(B, 98, 6, device=dev); cnt = torch.empty(B, dtype=torch.int32, device=dev)
+n = 16 * 1024 * 1024                     # 64 MiB of floats
+x = torch.randn(n + 4, device=dev); y = torch.empty(n + 4, device=dev)
+torch.cuda.synchronize()
+y[:n].copy_(x[:n]); torch.cuda.synchronize()          # calibration 1: 16 B per lane
+y[:n].copy_(x[1:n + 1]); torch.cuda.synchronize()     # calibration 2: 4 B per lane
+for _ in range(3):
+    lib.yh_loss_partials(pred.data_ptr(), gx.data_ptr(), gc.data_ptr(), om8.data_ptr(), grad.data_ptr(),
+                         ws.data_ptr(), ws.numel(), B, 7, 2, 20, 448, 5.0, 0.5, 1.0 / B, st)
+    torch.cuda.synchronize()
+for _ in range(3):
+    lib.yh_decode_nms(pred.data_ptr(), dets.data_ptr(), cnt.data_ptr(), None, MODE_REFERENCE, 0.5, 0.5,
+                      B, 7, 2, 20, 448, st)
+    torch.cuda.synchronize()
+print("calibration bytes per copy:", 4 * n, "obj cells:", int(om.sum()))

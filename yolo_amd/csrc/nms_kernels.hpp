@@ -44,7 +44,7 @@ struct NmsArgs {
     // per-image LDS region: byte offsets of the arrays inside it, and its size
     int off_keys, off_box, off_meta, off_alive, off_misc, off_ccls;
     int region_bytes;
-    int dbg_stop;  // profiling aid: leave after this phase (0 = run everything)
+    int dbg_stop;  // builds with -DYH_PHASE_PROBE only: leave after this phase (0 = run everything)
 };
 
 // ---- decode primitives shared by every kernel that forms candidates --------------
@@ -260,7 +260,9 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
         }
     }
 
+#ifdef YH_PHASE_PROBE
     if (a.dbg_stop == 1) { if (cvalid[0] && cscore[0] == 12345.f) a.keep_count[img] = ccl[0] + (int)cbox[0].l; return; }
+#endif
     // ---- phase B: keys, rank, segment start ---------------------------------------
     unsigned long long key[ITEMS], clsbase[ITEMS];
 #pragma unroll
@@ -288,7 +290,9 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
         }
     }
 
+#ifdef YH_PHASE_PROBE
     if (a.dbg_stop == 2) { if (rank[0] == 12345) a.keep_count[img] = seg[0]; return; }
+#endif
     // ---- phase C: scatter to rank order ---------------------------------------------
     int nv_local = 0, mp_local = 0;
 #pragma unroll
@@ -309,7 +313,9 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
     const int nvalid = misc[0];
     const int maxpos = misc[1];
 
+#ifdef YH_PHASE_PROBE
     if (a.dbg_stop == 3) return;
+#endif
     // ---- phase D: greedy suppression over sorted positions ----------------------------
     Box mybox[ITEMS];
     int4 mymeta[ITEMS];
@@ -395,7 +401,9 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
             pos_out[e] = pos;
         }
     }
+#ifdef YH_PHASE_PROBE
     if (a.dbg_stop == 4) { if (al[0] && mybox[0].l == 12345.f) a.keep_count[img] = 1; return; }
+#endif
 
     // ---- phase E: survivors go straight to their output rows; the rest is zero-filled ----
     // A row is 24 bytes, so 8-byte stores are always aligned; consecutive survivors

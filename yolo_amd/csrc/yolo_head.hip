@@ -270,7 +270,9 @@ int yh_decode_nms(const float* pred, float* dets, int32_t* keep_count, int32_t* 
     a.imgf = (float)img_size;
     a.conf_thr = conf_thresh;
     a.iou_thr = iou_thresh;
+#ifdef YH_PHASE_PROBE
     { const char* e = getenv("YH_NMS_STOP"); a.dbg_stop = e ? atoi(e) : 0; }
+#endif
     return launch_nms<0>(a, (hipStream_t)stream);
 }
 
