@@ -63,6 +63,8 @@ def parse():
                     help="steps captured into one HIP graph (the remainder of --steps runs on a 1-step graph)")
     ap.add_argument("--prewarm-seconds", type=float, default=0.3,
                     help="untimed steps run before the warm-up so the GPU clocks are at steady state")
+    ap.add_argument("--serial", action="store_true",
+                    help="run the loss and decode+NMS halves of the step on one stream instead of two")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--kernel-iters", type=int, default=200)
@@ -152,50 +154,62 @@ def main():
     log = LossLog(dev, capacity=every)
     reducer = LossAllReducer()
 
-    def step():
-        terms, grad = head.loss_fwd_bwd(pred, gx, gc, om, global_batch=global_batch, log=log)
-        dets, count = head.postprocess(pred, CONF_T, IOU_T, MODE_REFERENCE)
-        return terms, grad, dets, count
+    # The two halves of the step are independent readers of the head tensor (the
+    # loss writes the gradient and the loss sums, decode+NMS writes the detections),
+    # so they are enqueued on two HIP streams and overlap on the GPU; `--serial` puts
+    # them back on one stream.  Each half is captured `spg` steps per HIP graph.
+    s_loss = torch.cuda.Stream(dev)
+    s_nms = s_loss if args.serial else torch.cuda.Stream(dev)
+    keep = {}
 
-    # ---- build the step: HIP graphs of its three kernels, or eager launches -------
+    def loss_step():
+        keep["loss"] = head.loss_fwd_bwd(pred, gx, gc, om, global_batch=global_batch, log=log)
+
+    def nms_step():
+        keep["nms"] = head.postprocess(pred, CONF_T, IOU_T, MODE_REFERENCE)
+
     use_graph = not args.no_graph
-    side = torch.cuda.Stream(dev)
-    side.wait_stream(torch.cuda.current_stream(dev))
-    with torch.cuda.stream(side):
+    with torch.cuda.stream(s_loss):
         for _ in range(3):
-            outs = step()
-    torch.cuda.current_stream(dev).wait_stream(side)
+            loss_step()
+            nms_step()
     torch.cuda.synchronize()
-    graph_n, graph_1 = None, None
+    graphs = {}
     if use_graph:
         try:
-            graph_1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph_1):
-                outs = step()
-            graph_n = graph_1
-            if spg > 1:
-                graph_n = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_n):
-                    for _ in range(spg):
-                        outs = step()
+            for name, fn, st in (("loss", loss_step, s_loss), ("nms", nms_step, s_nms)):
+                for n in sorted({1, spg}):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=st):
+                        for _ in range(n):
+                            fn()
+                    graphs[(name, n)] = g
         except Exception as exc:  # capture unsupported: fall back to eager launches
             if rank == 0:
                 print(f"[bench] graph capture failed ({exc!r}); running eagerly", file=sys.stderr)
-            graph_n = graph_1 = None
+            graphs = {}
             use_graph, spg = False, 1
             torch.cuda.synchronize()
 
     def run_steps(n):
-        """Enqueue exactly n steps."""
-        nonlocal outs
+        """Enqueue exactly n steps: n loss passes on s_loss, n decode+NMS passes on s_nms."""
         if use_graph:
             for _ in range(n // spg):
-                graph_n.replay()
+                with torch.cuda.stream(s_loss):
+                    graphs[("loss", spg)].replay()
+                with torch.cuda.stream(s_nms):
+                    graphs[("nms", spg)].replay()
             for _ in range(n % spg):
-                graph_1.replay()
+                with torch.cuda.stream(s_loss):
+                    graphs[("loss", 1)].replay()
+                with torch.cuda.stream(s_nms):
+                    graphs[("nms", 1)].replay()
         else:
             for _ in range(n):
-                outs = step()
+                with torch.cuda.stream(s_loss):
+                    loss_step()
+                with torch.cuda.stream(s_nms):
+                    nms_step()
 
     def sync_all():
         if world > 1:
@@ -220,9 +234,11 @@ def main():
     while done < args.steps:
         n = min(every, args.steps - done)
         run_steps(n)
-        reducer.flush(log.ring, n)
+        with torch.cuda.stream(s_loss):          # ordered after the loss kernels that filled the ring
+            reducer.flush(log.ring, n)
         done += n
-    losses = reducer.results()                      # waits for the collectives (stream-ordered)
+    with torch.cuda.stream(s_loss):
+        losses = reducer.results()                  # waits for the collectives (stream-ordered)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -258,6 +274,7 @@ def main():
             "conf_thresh": CONF_T, "iou_thresh": IOU_T, "nms_mode": "reference",
             "parallelism": f"dp{world} by image, loss all-reduce every {every} steps",
             "launch": f"hip-graph, {spg} steps per graph" if use_graph else "eager",
+            "streams": 1 if args.serial else 2,
         },
         "loss": loss_value,
         "step_gbs": value * (loss_bytes_per_image() + nms_bytes_per_image()) / 1e9,

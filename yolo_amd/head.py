@@ -150,7 +150,8 @@ class YOLOv1Head(nn.Module):
         return ws
 
     # --------------------------------------------------------------------- loss
-    def _launch_loss(self, out, gt_norm_xywh, gt_cls_prob, obj_mask, inv_global_batch, log=None):
+    def _launch_loss(self, out, gt_norm_xywh, gt_cls_prob, obj_mask, inv_global_batch, log=None,
+                     finalize_stream=None):
         out = self._check_out(out)
         bsz, n = out.shape[0], self.n_grid
         _need(gt_norm_xywh, "gt_norm_xywh", torch.float32, (bsz, n, 1, 4))
@@ -177,22 +178,35 @@ class YOLOv1Head(nn.Module):
                 obj_mask.data_ptr(), grad.data_ptr(), ws.data_ptr(), ws.numel(), bsz,
                 self.n_cells, self.n_bboxes, self.n_classes, self.img_size, self.coord_coeff,
                 self.noobj_coeff, float(inv_global_batch), st))
+            fst = st
+            if finalize_stream is not None:
+                # the scalar reduction leaves the critical path: it runs on the side
+                # stream as soon as the partial rows exist
+                finalize_stream.wait_stream(torch.cuda.current_stream(out.device))
+                fst = finalize_stream.cuda_stream
             _lib.check(lib.yh_loss_finalize(
                 ws.data_ptr(), ws.numel(), bsz, self.n_cells, float(inv_global_batch),
                 terms.data_ptr(), None if log is None else log.ring.data_ptr(),
                 0 if log is None else log.capacity,
-                None if log is None else log.cursor.data_ptr(), st))
+                None if log is None else log.cursor.data_ptr(), fst))
         return terms, grad
 
     def loss_fwd_bwd(self, out, gt_norm_xywh, gt_cls_prob, obj_mask, global_batch=None,
-                     log: Optional[LossLog] = None):
+                     log: Optional[LossLog] = None,
+                     finalize_stream: Optional[torch.cuda.Stream] = None):
         """Functional form: one kernel pass returning ``(terms, grad)`` with
         terms = [coord_sum, conf_sum, cls_sum, total_sum, total/global_batch] and
         grad = d(total/global_batch)/d(out).  No autograd graph is recorded.
-        ``log`` receives the four sums as one more row (see LossLog)."""
+        ``log`` receives the four sums as one more row (see LossLog).
+
+        ``finalize_stream``: stream for the small kernel that adds the per-workgroup
+        loss rows.  Nothing downstream of the gradient needs the scalar, so it can
+        overlap whatever the current stream runs next; the caller makes the
+        current stream wait for it (``wait_stream``) before the next call of this
+        method or before reading ``terms``/the log."""
         gb = out.shape[0] if global_batch is None else int(global_batch)
         return self._launch_loss(out.detach(), gt_norm_xywh, gt_cls_prob, obj_mask,
-                                 1.0 / max(gb, 1), log)
+                                 1.0 / max(gb, 1), log, finalize_stream)
 
     def get_loss(self, image, gt_norm_xywh, gt_cls_prob, obj_mask, global_batch=None):
         """model.py:296-317: (coord + conf + cls) / B as a 0-d tensor that supports
