@@ -12,7 +12,9 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 import torch  # noqa: F401  -- must be imported first: its HIP runtime is the one the library binds to
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libyolohead.so")
+LIB_PATH = os.environ.get(
+    "YOLO_AMD_LIB",  # measurement builds only (tools/); the package ships and tests the path below
+    os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libyolohead.so"))
 
 # error codes of include/yolo_head.h
 YH_OK = 0

@@ -13,54 +13,39 @@ namespace yh {
 
 constexpr int LOSS_THREADS = 256;
 
-// BX_CT / C_CT > 0: predictor and class counts fixed at compile time (loops
-// unroll, repeated loads and exponentials are shared); 0: taken from nb_rt /
-// nc_rt at run time.
-template <int BX_CT, int C_CT>
-__device__ __forceinline__ void loss_cell(const float* __restrict__ p, float* __restrict__ g,
-                                          const float* __restrict__ gxywh,
-                                          const float* __restrict__ gcls, bool obj, int cell,
-                                          int S, int S2, int nb_rt, int nc_rt, float cellf,
-                                          float imgf, float lc, float ln, float inv_gb,
-                                          float& acc_coord, float& acc_conf, float& acc_cls) {
-    const int nb = BX_CT > 0 ? BX_CT : nb_rt;
-    const int nc = C_CT > 0 ? C_CT : nc_rt;
-    constexpr bool kStatic = BX_CT > 0 && C_CT > 0;
-    constexpr int kD = kStatic ? 5 * BX_CT + C_CT : 1;
+// A cell without object: only the no-object confidence term (model.py:270-274);
+// every other gradient of the cell is zero.  `logit(ch)` returns channel ch of
+// the cell, `g` points at the cell's gradient (channels S2 floats apart).
+template <class L>
+__device__ __forceinline__ void loss_noobj_cell(const L& logit, float* __restrict__ g, int S2,
+                                                int nb, int nc, float ln, float inv_gb,
+                                                float& acc_conf) {
+#pragma unroll
+    for (int k = 0; k < nb; ++k) {
+        const float conf = sigmoidf_(logit(5 * k + 4));
+        acc_conf += ln * (conf * conf);
+        g[(5 * k + 0) * S2] = 0.0f;
+        g[(5 * k + 1) * S2] = 0.0f;
+        g[(5 * k + 2) * S2] = 0.0f;
+        g[(5 * k + 3) * S2] = 0.0f;
+        g[(5 * k + 4) * S2] = 2.0f * ln * conf * (conf * (1.0f - conf)) * inv_gb;
+    }
+#pragma unroll
+    for (int j = 0; j < nc; ++j) g[(5 * nb + j) * S2] = 0.0f;
+}
+
+// A cell that holds an object: responsible predictor by IoU, coordinate,
+// objectness, no-object (other predictors) and class terms with all gradients
+// (model.py:190-294 and their autograd backward).  C_CT > 0 with C_CT % 4 == 0:
+// the class targets are fetched as float4 (gcls 16-byte aligned).
+template <int C_CT, class L>
+__device__ __forceinline__ void loss_obj_cell(const L& logit, float* __restrict__ g,
+                                              const float* __restrict__ gxywh,
+                                              const float* __restrict__ gcls, int cell, int S,
+                                              int S2, int nb, int nc, float cellf, float imgf,
+                                              float lc, float ln, float inv_gb, float& acc_coord,
+                                              float& acc_conf, float& acc_cls) {
     const int c0 = 5 * nb;
-
-    // Compile-time shape: all D logits of the cell are fetched up front, with no
-    // dependence on obj_mask, so the cell costs one memory round trip (plus one
-    // for the ground truth of an object cell); the lines are needed by
-    // neighbouring cells anyway.  Run-time shape: read on use.
-    float v[kD];
-    if constexpr (kStatic) {
-#pragma unroll
-        for (int ch = 0; ch < kD; ++ch) v[ch] = p[ch * S2];
-    }
-    auto logit = [&](int ch) -> float {
-        if constexpr (kStatic) return v[ch];
-        else return p[ch * S2];
-    };
-
-    if (!obj) {
-        // a cell without object: only the no-object confidence term (model.py:270-274)
-#pragma unroll
-        for (int k = 0; k < nb; ++k) {
-            const float conf = sigmoidf_(logit(5 * k + 4));
-            acc_conf += ln * (conf * conf);
-            g[(5 * k + 0) * S2] = 0.0f;
-            g[(5 * k + 1) * S2] = 0.0f;
-            g[(5 * k + 2) * S2] = 0.0f;
-            g[(5 * k + 3) * S2] = 0.0f;
-            g[(5 * k + 4) * S2] = 2.0f * ln * conf * (conf * (1.0f - conf)) * inv_gb;
-        }
-#pragma unroll
-        for (int j = 0; j < nc; ++j) g[(c0 + j) * S2] = 0.0f;
-        return;
-    }
-
-    // ---- object cell ------------------------------------------------------------
     // ground truth through the same decode as the predictions (model.py:261-262)
     const float4 gv = *reinterpret_cast<const float4*>(gxywh);
     float gtc[C_CT > 0 ? C_CT : 1];
@@ -150,55 +135,54 @@ __device__ __forceinline__ void loss_cell(const float* __restrict__ p, float* __
     float m = logit(c0);
 #pragma unroll
     for (int j = 1; j < nc; ++j) m = fmaxf(m, logit(c0 + j));
-    float s = 0.f;
+    float s = 0.f, dot = 0.f, l2 = 0.f;
+    if constexpr (C_CT > 0) {
+        // exponentials kept in registers, logits re-read from their (cheap) source
+        float e[C_CT];
 #pragma unroll
-    for (int j = 0; j < nc; ++j) s += exp_fast(logit(c0 + j) - m);
-    const float rs = rcp_fast(s);
-    float dot = 0.f, l2 = 0.f;
+        for (int j = 0; j < C_CT; ++j) {
+            e[j] = exp_fast(logit(c0 + j) - m);
+            s += e[j];
+        }
+        const float rs = rcp_fast(s);
 #pragma unroll
-    for (int j = 0; j < nc; ++j) {
-        const float pj = exp_fast(logit(c0 + j) - m) * rs;
-        const float d = pj - gtcls(j);
-        l2 += d * d;
-        dot += 2.0f * d * pj;
-    }
+        for (int j = 0; j < C_CT; ++j) {
+            e[j] *= rs;
+            const float d = e[j] - gtcls(j);
+            l2 += d * d;
+            dot += 2.0f * d * e[j];
+        }
 #pragma unroll
-    for (int j = 0; j < nc; ++j) {
-        const float pj = exp_fast(logit(c0 + j) - m) * rs;
-        g[(c0 + j) * S2] = pj * (2.0f * (pj - gtcls(j)) - dot) * inv_gb;
+        for (int j = 0; j < C_CT; ++j)
+            g[(c0 + j) * S2] = e[j] * (2.0f * (e[j] - gtcls(j)) - dot) * inv_gb;
+    } else {
+        for (int j = 0; j < nc; ++j) s += exp_fast(logit(c0 + j) - m);
+        const float rs = rcp_fast(s);
+        for (int j = 0; j < nc; ++j) {
+            const float pj = exp_fast(logit(c0 + j) - m) * rs;
+            const float d = pj - gtcls(j);
+            l2 += d * d;
+            dot += 2.0f * d * pj;
+        }
+        for (int j = 0; j < nc; ++j) {
+            const float pj = exp_fast(logit(c0 + j) - m) * rs;
+            g[(c0 + j) * S2] = pj * (2.0f * (pj - gtcls(j)) - dot) * inv_gb;
+        }
     }
     acc_cls += l2;
 }
 
-template <int BX_CT, int C_CT>
-__global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_kernel(
-    const float* __restrict__ pred, const float* __restrict__ gt_xywh,
-    const float* __restrict__ gt_cls, const uint8_t* __restrict__ obj_mask,
-    float* __restrict__ grad, float* __restrict__ partials, long long batch, int S, int nb_rt,
-    int nc_rt, int imgs_per_block, float cellf, float imgf, float lc, float ln, float inv_gb) {
-    const int nb = BX_CT > 0 ? BX_CT : nb_rt;
-    const int nc = C_CT > 0 ? C_CT : nc_rt;
-    const int S2 = S * S;
-    const long long D = 5 * nb + nc;
-    const long long img0 = (long long)blockIdx.x * imgs_per_block;
-    const int nitems = imgs_per_block * S2;
+// reads a cell's channels from the head tensor on use
+struct GlobalLogits {
+    const float* __restrict__ p;
+    int S2;
+    __device__ __forceinline__ float operator()(int ch) const { return p[ch * S2]; }
+};
 
-    float acc_coord = 0.f, acc_conf = 0.f, acc_cls = 0.f;
-    for (int item = threadIdx.x; item < nitems; item += LOSS_THREADS) {
-        const int gi = item / S2;
-        const int cell = item - gi * S2;
-        const long long img = img0 + gi;
-        if (img < batch) {
-            const long long tcell = img * S2 + cell;
-            const long long off = img * D * S2 + cell;
-            loss_cell<BX_CT, C_CT>(pred + off, grad + off, gt_xywh + tcell * 4,
-                                   gt_cls + tcell * nc, obj_mask[tcell] != 0, cell, S, S2, nb,
-                                   nc, cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf,
-                                   acc_cls);
-        }
-    }
-
-    // wave -> workgroup reduction in a fixed order
+// wave -> workgroup reduction of the three partial sums in a fixed order; one
+// row of `partials` per workgroup
+__device__ __forceinline__ void loss_block_reduce(float acc_coord, float acc_conf, float acc_cls,
+                                                  float* __restrict__ partials) {
     __shared__ float red[LOSS_THREADS / 64][3];
     acc_coord = wave_sum(acc_coord);
     acc_conf = wave_sum(acc_conf);
@@ -216,6 +200,78 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_kernel(
         for (int w = 0; w < LOSS_THREADS / 64; ++w) s += red[w][threadIdx.x];
         partials[(size_t)blockIdx.x * 4 + threadIdx.x] = s;
     }
+}
+
+// Run-time shape (any S, Bx, C within the limits): channels are read on use.
+__global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
+    const float* __restrict__ pred, const float* __restrict__ gt_xywh,
+    const float* __restrict__ gt_cls, const uint8_t* __restrict__ obj_mask,
+    float* __restrict__ grad, float* __restrict__ partials, long long batch, int S, int nb,
+    int nc, int imgs_per_block, float cellf, float imgf, float lc, float ln, float inv_gb) {
+    const int S2 = S * S;
+    const long long D = 5 * nb + nc;
+    const long long img0 = (long long)blockIdx.x * imgs_per_block;
+    const int nitems = imgs_per_block * S2;
+    float acc_coord = 0.f, acc_conf = 0.f, acc_cls = 0.f;
+    for (int item = threadIdx.x; item < nitems; item += LOSS_THREADS) {
+        const int gi = item / S2;
+        const int cell = item - gi * S2;
+        const long long img = img0 + gi;
+        if (img < batch) {
+            const long long tcell = img * S2 + cell;
+            const long long off = img * D * S2 + cell;
+            const GlobalLogits logit{pred + off, S2};
+            if (obj_mask[tcell] != 0)
+                loss_obj_cell<0>(logit, grad + off, gt_xywh + tcell * 4, gt_cls + tcell * nc, cell,
+                                 S, S2, nb, nc, cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf,
+                                 acc_cls);
+            else
+                loss_noobj_cell(logit, grad + off, S2, nb, nc, ln, inv_gb, acc_conf);
+        }
+    }
+    loss_block_reduce(acc_coord, acc_conf, acc_cls, partials);
+}
+
+// Compile-time shape.  Every lane fetches the D logits of its cell up front (one
+// memory round trip, independent of obj_mask) and keeps them in registers.  S is
+// a template parameter too: with S*S known, every channel of a cell is a constant
+// byte offset from the cell's address (no per-channel address arithmetic).
+// (Compacting the object cells of a workgroup into one wavefront through LDS was
+// measured slower here: the barriers and the single-wave object path lengthen
+// each workgroup's critical path more than the saved VALU work is worth.)
+template <int S, int BX, int C>
+__global__ __launch_bounds__(LOSS_THREADS, 4) void loss_fwd_bwd_kernel(
+    const float* __restrict__ pred, const float* __restrict__ gt_xywh,
+    const float* __restrict__ gt_cls, const uint8_t* __restrict__ obj_mask,
+    float* __restrict__ grad, float* __restrict__ partials, long long batch,
+    int imgs_per_block, float cellf, float imgf, float lc, float ln, float inv_gb) {
+    constexpr int D = 5 * BX + C;
+    constexpr int S2 = S * S;
+    const long long img0 = (long long)blockIdx.x * imgs_per_block;
+    const int nitems = imgs_per_block * S2;
+
+    float acc_coord = 0.f, acc_conf = 0.f, acc_cls = 0.f;
+    for (int item = threadIdx.x; item < nitems; item += LOSS_THREADS) {
+        const int gi = item / S2;
+        const int cell = item - gi * S2;
+        const long long img = img0 + gi;
+        if (img < batch) {
+            const long long tcell = img * S2 + cell;
+            const long long off = img * (long long)D * S2 + cell;
+            const float* p = pred + off;
+            float v[D];
+#pragma unroll
+            for (int ch = 0; ch < D; ++ch) v[ch] = p[ch * S2];
+            auto logit = [&](int ch) -> float { return v[ch]; };
+            if (obj_mask[tcell] != 0)
+                loss_obj_cell<C>(logit, grad + off, gt_xywh + tcell * 4, gt_cls + tcell * C, cell,
+                                 S, S2, BX, C, cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf,
+                                 acc_cls);
+            else
+                loss_noobj_cell(logit, grad + off, S2, BX, C, ln, inv_gb, acc_conf);
+        }
+    }
+    loss_block_reduce(acc_coord, acc_conf, acc_cls, partials);
 }
 
 __device__ __forceinline__ double wave_sum_f64(double v) {

@@ -142,14 +142,13 @@ int yh_loss_partials(const float* pred, const float* gt_xywh, const float* gt_cl
     const int g = loss_imgs_per_block(S);
     const float cellf = (float)(img_size / S);
     const float imgf = (float)img_size;
-    const bool fast = Bx == 2 && C == 20 && aligned(gt_cls, 16);
-    if (fast) {
-        hipLaunchKernelGGL((yh::loss_fwd_bwd_kernel<2, 20>), dim3((unsigned)rows),
+    if (S == 7 && Bx == 2 && C == 20 && aligned(gt_cls, 16)) {
+        hipLaunchKernelGGL((yh::loss_fwd_bwd_kernel<7, 2, 20>), dim3((unsigned)rows),
                            dim3(yh::LOSS_THREADS), 0, st, pred, gt_xywh, gt_cls, obj_mask,
-                           grad_pred, partials, (long long)batch, S, Bx, C, g, cellf, imgf,
+                           grad_pred, partials, (long long)batch, g, cellf, imgf,
                            lambda_coord, lambda_noobj, inv_global_batch);
     } else {
-        hipLaunchKernelGGL((yh::loss_fwd_bwd_kernel<0, 0>), dim3((unsigned)rows),
+        hipLaunchKernelGGL(yh::loss_fwd_bwd_generic_kernel, dim3((unsigned)rows),
                            dim3(yh::LOSS_THREADS), 0, st, pred, gt_xywh, gt_cls, obj_mask,
                            grad_pred, partials, (long long)batch, S, Bx, C, g, cellf, imgf,
                            lambda_coord, lambda_noobj, inv_global_batch);
