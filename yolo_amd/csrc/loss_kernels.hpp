@@ -133,8 +133,13 @@ __device__ __forceinline__ void loss_obj_cell(const L& logit, float* __restrict_
 
     // class term (model.py:278-294): squared error on the softmax
     float m = logit(c0);
+    if constexpr (C_CT > 0) {
 #pragma unroll
-    for (int j = 1; j < nc; ++j) m = fmaxf(m, logit(c0 + j));
+        for (int j = 1; j < C_CT; ++j) m = fmaxf(m, logit(c0 + j));
+    } else {
+#pragma unroll 8
+        for (int j = 1; j < nc; ++j) m = fmaxf(m, logit(c0 + j));
+    }
     float s = 0.f, dot = 0.f, l2 = 0.f;
     if constexpr (C_CT > 0) {
         // exponentials kept in registers, logits re-read from their (cheap) source
@@ -156,14 +161,19 @@ __device__ __forceinline__ void loss_obj_cell(const L& logit, float* __restrict_
         for (int j = 0; j < C_CT; ++j)
             g[(c0 + j) * S2] = e[j] * (2.0f * (e[j] - gtcls(j)) - dot) * inv_gb;
     } else {
+        // run-time class count: unrolled by 8 so that eight loads are in flight per
+        // round trip instead of one
+#pragma unroll 8
         for (int j = 0; j < nc; ++j) s += exp_fast(logit(c0 + j) - m);
         const float rs = rcp_fast(s);
+#pragma unroll 8
         for (int j = 0; j < nc; ++j) {
             const float pj = exp_fast(logit(c0 + j) - m) * rs;
             const float d = pj - gtcls(j);
             l2 += d * d;
             dot += 2.0f * d * pj;
         }
+#pragma unroll 8
         for (int j = 0; j < nc; ++j) {
             const float pj = exp_fast(logit(c0 + j) - m) * rs;
             g[(c0 + j) * S2] = pj * (2.0f * (pj - gtcls(j)) - dot) * inv_gb;

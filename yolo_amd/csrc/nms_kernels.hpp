@@ -42,7 +42,7 @@ struct NmsArgs {
     int nout;   // rows of dets per image
     float cellf, imgf, conf_thr, iou_thr;
     // per-image LDS region: byte offsets of the arrays inside it, and its size
-    int off_keys, off_box, off_meta, off_alive, off_misc, off_ccls;
+    int off_keys, off_box, off_meta, off_alive, off_misc, off_ccls, off_hist, off_segst;
     int region_bytes;
     int dbg_stop;  // builds with -DYH_PHASE_PROBE only: leave after this phase (0 = run everything)
 };
@@ -134,6 +134,8 @@ template <int NT, int ITEMS, int SRC, int BX_CT, int C_CT>
 __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int IPB = NMS_BLOCK / NT;  // images per workgroup
+    // class-bucketed ranking: a workgroup per image, class count known and bounded
+    constexpr bool kBucket = NT != 64 && SRC == 0;
     constexpr int NW = NT / 64;          // wavefronts per image
     const int sub = threadIdx.x / NT;
     const int t = threadIdx.x % NT;
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
     float4* sbox = reinterpret_cast<float4*>(region + a.off_box);
     int4* smeta = reinterpret_cast<int4*>(region + a.off_meta);
     unsigned long long* alive = reinterpret_cast<unsigned long long*>(region + a.off_alive);
-    int* misc = reinterpret_cast<int*>(region + a.off_misc);  // [0] valid count, [1] max pos
+    int* misc = reinterpret_cast<int*>(region + a.off_misc);  // [0] valid count, [1] max pos, [4..7] scan carries
     int* ccls = reinterpret_cast<int*>(region + a.off_ccls);
 
     const int nslot = a.nslot;
@@ -272,21 +274,80 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
         clsbase[e] = (unsigned long long)(unsigned int)ccl[e] << 48;
         key[e] = cvalid[e] ? (clsbase[e] | ((unsigned long long)sk << 16) | (unsigned int)n)
                            : ~0ull;
-        keys[n] = key[e];
+        if constexpr (!kBucket) keys[n] = key[e];
     }
     group_sync<NT>();
     int rank[ITEMS], seg[ITEMS];
 #pragma unroll
     for (int e = 0; e < ITEMS; ++e) { rank[e] = 0; seg[e] = 0; }
-    // every lane reads the same LDS address per iteration (a broadcast); unrolled so
-    // that several reads are in flight
-#pragma unroll 8
-    for (int j = 0; j < nslot; ++j) {
-        const unsigned long long kj = keys[j];
+    if constexpr (kBucket) {
+        // Many candidates per image: bucket them by class first, so that a candidate
+        // is ranked against the members of its own class only (N * segment length
+        // comparisons instead of N * N).
+        int* hist = reinterpret_cast<int*>(region + a.off_hist);    // per class: count, then fill cursor
+        int* segst = reinterpret_cast<int*>(region + a.off_segst);  // per class: first sorted position
+        int* wtot = misc + 4;                                       // per wavefront: scan carry
+        const int nc = a.nc;
+        for (int c = t; c < nc; c += NT) hist[c] = 0;
+        group_sync<NT>();
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e)
+            if (cvalid[e]) atomicAdd(&hist[ccl[e]], 1);
+        group_sync<NT>();
+        // exclusive prefix sum over the classes: a contiguous chunk per thread,
+        // shuffle scan per wavefront, carries through LDS
+        const int chunk = (nc + NT - 1) / NT;
+        const int cbeg = t * chunk;
+        int local = 0;
+        for (int q = 0; q < chunk; ++q)
+            if (cbeg + q < nc) local += hist[cbeg + q];
+        int incl = local;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) wtot[wv] = incl;
+        group_sync<NT>();
+        int run = incl - local;
+        for (int w = 0; w < wv; ++w) run += wtot[w];
+        for (int q = 0; q < chunk; ++q) {
+            const int c = cbeg + q;
+            if (c < nc) {
+                const int h = hist[c];
+                segst[c] = run;
+                run += h;
+                hist[c] = 0;   // becomes the fill cursor of the bucket
+            }
+        }
+        group_sync<NT>();
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e)
+            if (cvalid[e]) keys[segst[ccl[e]] + atomicAdd(&hist[ccl[e]], 1)] = key[e];
+        group_sync<NT>();
+        // rank inside the bucket; the bucket order itself does not matter
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
-            rank[e] += kj < key[e] ? 1 : 0;
-            seg[e] += kj < clsbase[e] ? 1 : 0;
+            if (cvalid[e]) {
+                const int s0 = segst[ccl[e]];
+                const int n = hist[ccl[e]];
+                int cnt = 0;
+                for (int j = 0; j < n; ++j) cnt += keys[s0 + j] < key[e] ? 1 : 0;
+                rank[e] = s0 + cnt;
+                seg[e] = s0;
+            }
+        }
+    } else {
+        // every lane reads the same LDS address per iteration (a broadcast); unrolled
+        // so that several reads are in flight
+#pragma unroll 8
+        for (int j = 0; j < nslot; ++j) {
+            const unsigned long long kj = keys[j];
+#pragma unroll
+            for (int e = 0; e < ITEMS; ++e) {
+                rank[e] += kj < key[e] ? 1 : 0;
+                seg[e] += kj < clsbase[e] ? 1 : 0;
+            }
         }
     }
 

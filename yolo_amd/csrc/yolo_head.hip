@@ -53,9 +53,13 @@ void nms_layout(yh::NmsArgs& a, int slot_pad) {
     a.off_alive = off;
     off += round16((slot_pad / 64) * 8);
     a.off_misc = off;
-    off += 16;
+    off += 32;
     a.off_ccls = off;
     off += round16(a.S * a.S * 4);
+    a.off_hist = off;     // class histogram / bucket cursors and bucket starts (fused path)
+    off += round16(a.nc * 4);
+    a.off_segst = off;
+    off += round16(a.nc * 4);
     a.region_bytes = off;
 }
 
