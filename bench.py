@@ -65,6 +65,8 @@ def parse():
                     help="untimed steps run before the warm-up so the GPU clocks are at steady state")
     ap.add_argument("--serial", action="store_true",
                     help="run the loss and decode+NMS halves of the step on one stream instead of two")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--kernel-iters", type=int, default=200)
@@ -138,12 +140,23 @@ def main():
     from yolo_amd import MODE_REFERENCE, LossLog, YOLOv1Head, _lib, synth
     from yolo_amd.dist import LossAllReducer
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal aid: BENCH_SINGLE_DEVICE=1 puts every rank on GPU 0 (with --backend gloo),
+    # so the multi-process path can be exercised on a one-GPU machine
+    dev_index = 0 if os.environ.get("BENCH_SINGLE_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
+    def say(msg):
+        if args.verbose:
+            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    say(f"process group ready, world {world}, device {dev}")
     batch = args.batch
     global_batch = batch * world
     head = YOLOv1Head(IMG, S, BX, C)
@@ -180,7 +193,9 @@ def main():
             for name, fn, st in (("loss", loss_step, s_loss), ("nms", nms_step, s_nms)):
                 for n in sorted({1, spg}):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=st):
+                    # thread_local: the process group's watchdog thread may touch the HIP
+                    # runtime while this thread captures
+                    with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
                         for _ in range(n):
                             fn()
                     graphs[(name, n)] = g
@@ -218,6 +233,7 @@ def main():
         if world > 1:
             dist.barrier()
 
+    say(f"step built ({'graphs' if use_graph else 'eager'})")
     # untimed: bring the clocks up, then the W warm-up steps
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < args.prewarm_seconds:
@@ -228,6 +244,7 @@ def main():
     log.reset()
 
     # ---- timed region: exactly K steps ------------------------------------------
+    say("warm-up done")
     sync_all()
     t0 = time.perf_counter()
     done = 0
@@ -243,11 +260,13 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64,
+                      device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
+    say(f"timed region done: {elapsed:.4f} s")
     assert losses.shape == (args.steps, 4), losses.shape
     loss_value = float(losses[-1, 3].item()) / global_batch
     if not torch.isfinite(losses).all():

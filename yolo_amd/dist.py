@@ -54,7 +54,14 @@ class LossAllReducer:
         rows = ring[:n].clone()        # the ring is free for the next steps
         work = None
         if self.world_size > 1:
-            work = dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if rows.is_cuda and dist.get_backend(self.group) == "gloo":
+                # gloo moves host memory: stage through the CPU (a rehearsal path; the
+                # GPU backend is "nccl" = RCCL and reduces the device buffer in place)
+                host = rows.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                rows = host.to(rows.device)
+            else:
+                work = dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append((work, rows))
 
     def results(self) -> torch.Tensor:
