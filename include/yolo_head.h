@@ -120,6 +120,24 @@ int yh_loss_finalize(const void* workspace, size_t workspace_bytes, int64_t batc
 int yh_scale_grad(float* grad, const float* scale, int64_t n, void* stream);
 
 /*
+ * Target encoder: ground-truth boxes -> the three loss inputs, on the device.
+ * Restates ltrb_to_xywh (data.py:173-183), normalize_xywh (data.py:185-194) and
+ * get_object_mask (model.py:213-222); the reference leaves this step unfinished
+ * on the host (data.py:196-203).
+ *   gt_ltrb  (batch, M, 4) pixel boxes l,t,r,b;  gt_label (batch, M) int32;
+ *   gt_count (batch) int32: boxes m >= gt_count[b] are padding and ignored.
+ * The cell of a box is [cx // cell_size, cy // cell_size] (first grid axis = x,
+ * flat index x_cell*S + y_cell, clamped into the grid); when several boxes fall
+ * into one cell the LAST one wins.  Cells without a box get zeros.  A label
+ * outside [0, C) leaves the class row all zero.  Outputs: gt_xywh (16-byte
+ * aligned), gt_cls, obj_mask as yh_loss_fwd_bwd reads them.  Every value is
+ * bit-identical to the PyTorch arithmetic of the reference (no transcendental).
+ */
+int yh_encode_targets(const float* gt_ltrb, const int32_t* gt_label, const int32_t* gt_count,
+                      float* gt_xywh, float* gt_cls, uint8_t* obj_mask, int64_t batch, int M,
+                      int S, int C, int img_size, void* stream);
+
+/*
  * Dense grid decode.  Replaces get_ltrb (model.py:150-188), get_confidence
  * (:242-250), get_classification_prob (:278-286), _get_classification_index
  * (:392-394), get_confidence_mask (:379-382) and get_max_confidence_ltrb

@@ -229,6 +229,41 @@ def loss_and_grad(out, gt_norm_xywh, gt_cls_prob, obj_mask, global_batch=None,
 
 
 # ----------------------------------------------------------------------------
+# target encoding -- data.py:173-194, model.py:213-222
+# ----------------------------------------------------------------------------
+def encode_targets(gt_ltrb, gt_label, gt_count, n_cells=7, n_classes=20, img_size=448):
+    """Per-image, per-box loop with the reference's own tensor expressions:
+    ltrb_to_xywh (data.py:173-183), normalize_xywh (data.py:185-194), the cell
+    index of get_object_mask (model.py:217-221: [x // cell_size, y // cell_size],
+    first axis = x).  One box per cell (data.py:32): a later box overwrites an
+    earlier one.  Indices are clamped into the grid (the reference would raise).
+    gt_ltrb (B, M, 4), gt_label (B, M), gt_count (B,)."""
+    bsz = gt_ltrb.shape[0]
+    n = n_cells * n_cells
+    cell_size = img_size // n_cells
+    gt_norm_xywh = torch.zeros(bsz, n, 1, 4)
+    gt_cls_prob = torch.zeros(bsz, n, 1, n_classes)
+    obj_mask = torch.zeros(bsz, n, 1, 1, dtype=torch.bool)
+    for b in range(bsz):
+        for m in range(int(gt_count[b])):
+            ltrb = gt_ltrb[b, m].to(torch.float32)
+            xywh = torch.stack([(ltrb[0] + ltrb[2]) / 2, (ltrb[1] + ltrb[3]) / 2,
+                                ltrb[2] - ltrb[0], ltrb[3] - ltrb[1]], dim=-1)
+            norm = torch.stack([xywh[0] % cell_size / cell_size, xywh[1] % cell_size / cell_size,
+                                xywh[2] / img_size, xywh[3] / img_size], dim=-1)
+            xc = min(max(int((xywh[0] // cell_size).long()), 0), n_cells - 1)
+            yc = min(max(int((xywh[1] // cell_size).long()), 0), n_cells - 1)
+            cell = xc * n_cells + yc
+            gt_norm_xywh[b, cell, 0] = norm
+            gt_cls_prob[b, cell, 0] = 0.0
+            lab = int(gt_label[b, m])
+            if 0 <= lab < n_classes:
+                gt_cls_prob[b, cell, 0, lab] = 1.0
+            obj_mask[b, cell, 0, 0] = True
+    return gt_norm_xywh, gt_cls_prob, obj_mask
+
+
+# ----------------------------------------------------------------------------
 # post-processing -- model.py:379-394
 # ----------------------------------------------------------------------------
 def get_confidence_mask(out, conf_thresh, n_bboxes=2):

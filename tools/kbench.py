@@ -23,8 +23,12 @@ def b2b(fn, iters=300):
     for _ in range(iters): fn()
     b.record(); torch.cuda.synchronize()
     return 1e3 * a.elapsed_time(b) / iters
+lt, lb, ct = (t.to(dev) for t in synth.make_gt_boxes(B, seed=1))
+lb = lb.to(torch.int32); ct = ct.to(torch.int32)
+ex = torch.empty(B, 49, 1, 4, device=dev); ec = torch.empty(B, 49, 1, 20, device=dev); em = torch.empty(B, 49, 1, 1, dtype=torch.uint8, device=dev)
+def k_enc(): lib.yh_encode_targets(lt.data_ptr(), lb.data_ptr(), ct.data_ptr(), ex.data_ptr(), ec.data_ptr(), em.data_ptr(), B, lt.shape[1], 7, 20, 448, st)
 which = sys.argv[1:] or ["loss", "fin", "nms"]
 out = []
 for w in which:
-    out.append("%s %.2f us" % (w, b2b({"loss": k_loss, "fin": k_fin, "nms": k_nms}[w])))
+    out.append("%s %.2f us" % (w, b2b({"loss": k_loss, "fin": k_fin, "nms": k_nms, "enc": k_enc}[w])))
 print(os.environ.get("KB_TAG", ""), " | ".join(out))

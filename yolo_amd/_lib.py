@@ -49,6 +49,8 @@ SIGNATURES = {
     "yh_loss_finalize": (c_int, [c_void_p, c_size_t, c_int64, c_int, c_float, c_void_p, c_void_p,
                                  c_int, c_void_p, c_void_p]),
     "yh_scale_grad": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "yh_encode_targets": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "yh_decode_grid": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_float, c_int64, c_int, c_int, c_int, c_int,
                                c_void_p]),

@@ -11,6 +11,7 @@
 #include "decode_kernels.hpp"
 #include "loss_kernels.hpp"
 #include "nms_kernels.hpp"
+#include "target_kernels.hpp"
 
 namespace {
 
@@ -206,6 +207,27 @@ int yh_scale_grad(float* grad, const float* scale, int64_t n, void* stream) {
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(yh::scale_grad_kernel, dim3((unsigned)blocks), dim3(256), 0,
                        (hipStream_t)stream, grad, scale, (long long)n);
+    return launch_status();
+}
+
+int yh_encode_targets(const float* gt_ltrb, const int32_t* gt_label, const int32_t* gt_count,
+                      float* gt_xywh, float* gt_cls, uint8_t* obj_mask, int64_t batch, int M,
+                      int S, int C, int img_size, void* stream) {
+    if (const int rc = check_shape(batch, S, 1, C, img_size)) return rc;
+    if (M < 0 || M > 65536) return YH_ERR_SHAPE;
+    if (batch == 0) return YH_OK;
+    if (!gt_count || !gt_xywh || !gt_cls || !obj_mask || (M > 0 && (!gt_ltrb || !gt_label)))
+        return YH_ERR_NULL;
+    if (!aligned(gt_ltrb, 16) || !aligned(gt_xywh, 16) || !aligned(gt_label, 4) ||
+        !aligned(gt_count, 4) || !aligned(gt_cls, 4))
+        return YH_ERR_ALIGN;
+    const int64_t total = batch * S * S;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    const int vec4 = (C % 4 == 0 && aligned(gt_cls, 16)) ? 1 : 0;
+    hipLaunchKernelGGL(yh::encode_targets_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, gt_ltrb, gt_label, gt_count, gt_xywh, gt_cls, obj_mask,
+                       (long long)batch, M, S, C, (float)(img_size / S), (float)img_size, vec4);
     return launch_status();
 }
 

@@ -223,6 +223,33 @@ class YOLOv1Head(nn.Module):
         self.last_loss_terms = terms
         return terms[4]
 
+    # ------------------------------------------------------------------ targets
+    def encode_targets(self, gt_ltrb, gt_label, gt_count):
+        """Ground truth -> loss inputs on the GPU (data.py:173-194, model.py:213-222).
+
+        gt_ltrb (B, M, 4) f32 pixel boxes, gt_label (B, M) integer labels, gt_count (B,)
+        number of real boxes per image (padding after them).  Returns gt_norm_xywh
+        (B, S*S, 1, 4), gt_cls_prob (B, S*S, 1, C), obj_mask (B, S*S, 1, 1) bool;
+        the last box that falls into a cell wins."""
+        _need(gt_ltrb, "gt_ltrb", torch.float32)
+        if gt_ltrb.dim() != 3 or gt_ltrb.shape[2] != 4:
+            raise ValueError(f"gt_ltrb: expected shape (B, M, 4), got {tuple(gt_ltrb.shape)}")
+        bsz, m, dev = gt_ltrb.shape[0], gt_ltrb.shape[1], gt_ltrb.device
+        gt_label = gt_label.to(device=dev, dtype=torch.int32).contiguous()
+        gt_count = gt_count.to(device=dev, dtype=torch.int32).contiguous()
+        _need(gt_label, "gt_label", torch.int32, (bsz, m))
+        _need(gt_count, "gt_count", torch.int32, (bsz,))
+        n = self.n_grid
+        gx = torch.empty(bsz, n, 1, 4, dtype=torch.float32, device=dev)
+        gc = torch.empty(bsz, n, 1, self.n_classes, dtype=torch.float32, device=dev)
+        om = torch.empty(bsz, n, 1, 1, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().yh_encode_targets(
+                gt_ltrb.data_ptr(), gt_label.data_ptr(), gt_count.data_ptr(), gx.data_ptr(),
+                gc.data_ptr(), om.data_ptr(), bsz, m, self.n_cells, self.n_classes,
+                self.img_size, _stream(dev)))
+        return gx, gc, om.view(torch.bool)
+
     # ------------------------------------------------------------------- decode
     def _decode(self, out, want, conf_thresh=0.0):
         out = self._check_out(out.detach())
