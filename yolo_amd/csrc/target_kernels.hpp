@@ -29,6 +29,89 @@ __device__ __forceinline__ float remainder_f32(float a, float b) {
     return mod;
 }
 
+// one box: ltrb_to_xywh (data.py:173-183), its cell (model.py:217-221) and
+// normalize_xywh (data.py:185-194)
+__device__ __forceinline__ int encode_box(const float4 b, int S, float cellf, float imgf,
+                                          float4& norm) {
+    const float cx = (b.x + b.z) / 2.0f;
+    const float cy = (b.y + b.w) / 2.0f;
+    int xc = (int)floordiv_f32(cx, cellf);
+    int yc = (int)floordiv_f32(cy, cellf);
+    xc = xc < 0 ? 0 : (xc > S - 1 ? S - 1 : xc);
+    yc = yc < 0 ? 0 : (yc > S - 1 ? S - 1 : yc);
+    norm.x = remainder_f32(cx, cellf) / cellf;
+    norm.y = remainder_f32(cy, cellf) / cellf;
+    norm.z = (b.z - b.x) / imgf;
+    norm.w = (b.w - b.y) / imgf;
+    return xc * S + yc;
+}
+
+// Tiled encoder for the usual case of few boxes per image (M <= 64): a workgroup
+// owns G consecutive images.  Phase 1 encodes every box once (one lane per box)
+// into LDS; phase 2 gives every cell its last matching box and writes xywh and
+// the object mask; phase 3 writes the class rows of the whole tile as one
+// contiguous, fully coalesced range (a lane computes the four one-hot values of
+// its float4 from the winner label of that cell).
+__global__ __launch_bounds__(256) void encode_targets_tiled_kernel(
+    const float* __restrict__ gt_ltrb, const int32_t* __restrict__ gt_label,
+    const int32_t* __restrict__ gt_count, float* __restrict__ gt_xywh,
+    float* __restrict__ gt_cls, uint8_t* __restrict__ obj_mask, long long batch, int M, int S,
+    int C, float cellf, float imgf, int G, int cls_vec4) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
+    const int S2 = S * S;
+    float4* e_norm = reinterpret_cast<float4*>(tsm);                 // [G*M]
+    int* e_cell = reinterpret_cast<int*>(tsm + (size_t)G * M * 16);  // [G*M]
+    int* e_label = e_cell + G * M;                                   // [G*M]
+    int* w_label = e_label + G * M;                                  // [G*S2]
+    const long long img0 = (long long)blockIdx.x * G;
+    const int nimg = (int)((batch - img0) < G ? (batch - img0) : G);
+
+    for (int i = threadIdx.x; i < nimg * M; i += 256) {
+        const int gi = i / M, m = i - gi * M;
+        const long long img = img0 + gi;
+        int n = gt_count[img];
+        n = n < 0 ? 0 : (n > M ? M : n);
+        int cell = -1;
+        if (m < n) {
+            float4 norm;
+            cell = encode_box(reinterpret_cast<const float4*>(gt_ltrb)[img * M + m], S, cellf, imgf, norm);
+            e_norm[i] = norm;
+            e_label[i] = gt_label[img * M + m];
+        }
+        e_cell[i] = cell;
+    }
+    __syncthreads();
+    for (int item = threadIdx.x; item < nimg * S2; item += 256) {
+        const int gi = item / S2, cell = item - gi * S2;
+        int win = -1;
+        for (int m = 0; m < M; ++m) win = e_cell[gi * M + m] == cell ? m : win;
+        const long long g = (img0 + gi) * S2 + cell;
+        reinterpret_cast<float4*>(gt_xywh)[g] =
+            win >= 0 ? e_norm[gi * M + win] : make_float4(0.f, 0.f, 0.f, 0.f);
+        obj_mask[g] = win >= 0 ? 1 : 0;
+        w_label[item] = win >= 0 ? e_label[gi * M + win] : -1;
+    }
+    __syncthreads();
+    float* rows = gt_cls + img0 * (long long)S2 * C;
+    const int nfl = nimg * S2 * C;
+    if (cls_vec4) {
+        for (int q = threadIdx.x; q < nfl / 4; q += 256) {
+            const int f = q * 4;
+            const int item = f / C, j = f - item * C;
+            const int lab = w_label[item];
+            reinterpret_cast<float4*>(rows)[q] =
+                make_float4(lab == j ? 1.f : 0.f, lab == j + 1 ? 1.f : 0.f,
+                            lab == j + 2 ? 1.f : 0.f, lab == j + 3 ? 1.f : 0.f);
+        }
+    } else {
+        for (int f = threadIdx.x; f < nfl; f += 256) {
+            const int item = f / C, j = f - item * C;
+            rows[f] = w_label[item] == j ? 1.f : 0.f;
+        }
+    }
+}
+
+// General encoder (any M): one lane per (image, cell) scans the image's boxes.
 __global__ __launch_bounds__(256) void encode_targets_kernel(
     const float* __restrict__ gt_ltrb, const int32_t* __restrict__ gt_label,
     const int32_t* __restrict__ gt_count, float* __restrict__ gt_xywh,

@@ -221,10 +221,19 @@ int yh_encode_targets(const float* gt_ltrb, const int32_t* gt_label, const int32
     if (!aligned(gt_ltrb, 16) || !aligned(gt_xywh, 16) || !aligned(gt_label, 4) ||
         !aligned(gt_count, 4) || !aligned(gt_cls, 4))
         return YH_ERR_ALIGN;
+    const int vec4 = (C % 4 == 0 && aligned(gt_cls, 16)) ? 1 : 0;
+    if (M >= 1 && M <= 64) {
+        const int g = loss_imgs_per_block(S);
+        const size_t lds = (size_t)g * M * 24 + (size_t)g * S * S * 4;
+        hipLaunchKernelGGL(yh::encode_targets_tiled_kernel, dim3((unsigned)((batch + g - 1) / g)),
+                           dim3(256), lds, (hipStream_t)stream, gt_ltrb, gt_label, gt_count,
+                           gt_xywh, gt_cls, obj_mask, (long long)batch, M, S, C,
+                           (float)(img_size / S), (float)img_size, g, vec4);
+        return launch_status();
+    }
     const int64_t total = batch * S * S;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    const int vec4 = (C % 4 == 0 && aligned(gt_cls, 16)) ? 1 : 0;
     hipLaunchKernelGGL(yh::encode_targets_kernel, dim3((unsigned)blocks), dim3(256), 0,
                        (hipStream_t)stream, gt_ltrb, gt_label, gt_count, gt_xywh, gt_cls, obj_mask,
                        (long long)batch, M, S, C, (float)(img_size / S), (float)img_size, vec4);
