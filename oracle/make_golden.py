@@ -18,8 +18,9 @@ Fixtures (inputs AND the reference's outputs; data only):
                     get_confidence_mask, _get_classification_index
   g4_objmask.npz    get_object_mask
   g5_targets.npz    VOC2012Dataset.ltrb_to_xywh / normalize_xywh
-  g6_terms.npz      reference get_coordinate_loss / get_classification_loss run
-                    with two documented patches (see below)
+  g6_terms.npz      reference get_coordinate_loss / get_classification_loss /
+                    get_confidence_loss / get_loss run with documented patches
+                    (see below): the composition lines are the reference's own
   g7_oracle_cfg1.npz  NOT from the reference: the oracle's own outputs at
                     config 1 (batch 16), kept as a regression vector and as the
                     input/expected pair the GPU tests replay.
@@ -170,9 +171,29 @@ def main():
     ref_coord = head.get_coordinate_loss(pred, gt_norm_xywh=gx, resp_mask=resp)
     ref_model.obj_mask = om
     ref_cls = head.get_classification_loss(pred, gt_cls_prob=gc)
+    # Patch 3 (repairs R1-R3, R5): get_confidence_loss (model.py:252-276) calls
+    #   self.get_ltrb / self.denormalize_xywh on batched tensors (the reference's
+    #   versions take one image), the pairwise get_iou, and reads a module-level
+    #   ``gt_norm_xywh``.  The three helpers are replaced by the oracle's batched /
+    #   per-cell forms (each pinned bit-for-bit by g1/g2) and the name is injected;
+    #   lines 265-276 -- pred_conf, resp_mask * mse(conf, iou),
+    #   noobj_coeff * (~resp_mask) * mse(conf, 0) -- then run as written.
+    head.get_ltrb = lambda o: ref_cpu.get_ltrb(o, 7, 2, 448)
+    head.denormalize_xywh = lambda n: ref_cpu.denormalize_xywh(n, 7, 448)
+    ref_model.get_iou = lambda a, b: ref_cpu.iou_elementwise(a, b)[..., None]
+    ref_model.gt_norm_xywh = gx
+    ref_conf = head.get_confidence_loss(pred, resp_mask=resp)
+    # Patch 4 (repair R4): get_loss (model.py:296-317) passes keywords that
+    #   _get_responsibility_mask does not accept; it is replaced by a function with
+    #   those keywords that returns the oracle's mask.  ``self(image)`` is the identity
+    #   here (no backbone).  Lines 311-317 then run as written, print included.
+    head._get_responsibility_mask = lambda out, gt_norm_xywh, obj_mask: resp
+    head.forward = lambda image: image
+    ref_total = head.get_loss(pred, gt_norm_xywh=gx, gt_cls_prob=gc, obj_mask=om)
     np.savez(os.path.join(OUT, "g6_terms.npz"), pred=pred.numpy(), gt_norm_xywh=gx.numpy(),
              gt_cls_prob=gc.numpy(), obj_mask=om.numpy(), resp_mask=resp.numpy(),
-             coord=ref_coord.numpy(), cls=ref_cls.numpy())
+             coord=ref_coord.numpy(), cls=ref_cls.numpy(), conf=ref_conf.numpy(),
+             loss=ref_total.numpy())
 
     # ---- G7: oracle regression vector at config 1 (NOT reference output) ----
     res = ref_cpu.loss_and_grad(pred, gx, gc, om)

@@ -9,9 +9,12 @@ Parity status: the reference holds no tests or golden vectors for this path.
 Every primitive below that the reference can execute is pinned by fixtures
 generated from the reference itself (``oracle/make_golden.py`` ->
 ``tests/golden/*.npz``).  The reference's ``get_loss`` and its three loss
-terms raise as committed, so their *composition* (about 15 lines, the repairs
-R1-R7 listed below) is pinned only by this file; NMS has no counterpart in the
-reference at all -> "parity unpinned" for the NMS keep rule.
+terms raise as committed; they are pinned by running the reference's own
+composition lines with the helper substitutions the repairs R1-R7 below imply
+(fixture g6: coordinate, confidence, class terms and the total -- the patches
+are listed in make_golden.py).  What no fixture can pin is the choice of the
+repairs themselves.  NMS has no counterpart in the reference at all ->
+"parity unpinned" for the NMS keep rule.
 
 Repairs relative to the reference source (reference: /root/reference):
   R1  the decode is batched: normalised xywh has shape (B, S*S, Bx, 4) with

@@ -48,10 +48,12 @@ def test_config1_matches_oracle_and_golden(dev, golden):
     assert abs(terms[4].item() - float(g["loss"])) <= RTOL * abs(float(g["loss"]))
     gg = torch.from_numpy(g["grad"])
     assert (grad - gg).abs().max().item() <= RTOL * gg.abs().max().item()
-    # the two terms that the reference's own code produced (golden g6)
+    # the terms and the total that the reference's own composition lines produced (golden g6)
     t6 = golden("g6_terms.npz")
     assert abs(terms[0].item() - float(t6["coord"])) <= RTOL * float(t6["coord"])
+    assert abs(terms[1].item() - float(t6["conf"])) <= RTOL * float(t6["conf"])
     assert abs(terms[2].item() - float(t6["cls"])) <= RTOL * float(t6["cls"])
+    assert abs(terms[4].item() - float(t6["loss"])) <= RTOL * float(t6["loss"])
 
 
 def test_fp64_oracle_agrees(dev):

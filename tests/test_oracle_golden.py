@@ -95,6 +95,10 @@ def test_g6_terms_through_reference_code(golden):
     assert torch.equal(resp, t(g["resp_mask"]))
     assert torch.equal(coord, t(g["coord"]))
     assert torch.equal(cls, t(g["cls"]))
+    # the reference's own composition lines for the confidence term (model.py:265-276)
+    # and for the total (model.py:311-317), run with the patches make_golden.py lists
+    assert torch.equal(conf, t(g["conf"]))
+    assert torch.equal(ref_cpu.get_loss(pred, gx, gc, om), t(g["loss"]))
 
 
 def test_g6_inputs_are_the_seeded_synthetic_ones(golden):
