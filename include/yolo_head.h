@@ -120,6 +120,22 @@ int yh_loss_finalize(const void* workspace, size_t workspace_bytes, int64_t batc
 int yh_scale_grad(float* grad, const float* scale, int64_t n, void* stream);
 
 /*
+ * Pairwise box geometry.  Replaces eval.get_area (eval.py:22-32),
+ * get_intersection_area (:35-50), get_iou (:53-65) and get_giou (:68-83); the
+ * fp32 results are bit-identical to the reference's PyTorch expressions (IEEE
+ * division, no fused multiply-add).
+ *   ltrb1 (N, 4), ltrb2 (M, 4), both 16-byte aligned; out (N, M) row-major.
+ *   kind: YH_BOX_IOU, YH_BOX_GIOU or YH_BOX_INTERSECTION.
+ * yh_box_area: out[i] = max(r-l, 0) * max(b-t, 0) for n boxes.
+ */
+#define YH_BOX_IOU 0
+#define YH_BOX_GIOU 1
+#define YH_BOX_INTERSECTION 2
+int yh_pairwise_boxes(const float* ltrb1, const float* ltrb2, float* out, int64_t N, int64_t M,
+                      int kind, void* stream);
+int yh_box_area(const float* ltrb, float* out, int64_t n, void* stream);
+
+/*
  * Target encoder: ground-truth boxes -> the three loss inputs, on the device.
  * Restates ltrb_to_xywh (data.py:173-183), normalize_xywh (data.py:185-194) and
  * get_object_mask (model.py:213-222); the reference leaves this step unfinished

@@ -12,7 +12,7 @@ attributes ``__init__`` sets, model.py:107-114) -- the head methods use nothing
 else.
 
 Fixtures (inputs AND the reference's outputs; data only):
-  g1_iou.npz        eval.get_area / get_intersection_area / get_iou
+  g1_iou.npz        eval.get_area / get_intersection_area / get_iou / get_giou
   g2_decode.npz     YOLOv1.get_norm_xywh, denormalize_xywh, xywh_to_ltrb
   g3_head.npz       get_confidence, get_classification_prob,
                     get_confidence_mask, _get_classification_index
@@ -101,6 +101,7 @@ def main():
         area1=ref_eval.get_area(b1).numpy(), area2=ref_eval.get_area(b2).numpy(),
         inter=ref_eval.get_intersection_area(b1, b2).numpy(),
         iou=ref_eval.get_iou(b1, b2).numpy(),
+        giou=ref_eval.get_giou(b1, b2).numpy(),
     )
 
     # ---- G2: decode -------------------------------------------------------

@@ -71,6 +71,22 @@ def get_iou(ltrb1: torch.Tensor, ltrb2: torch.Tensor) -> torch.Tensor:
     return torch.where(union == 0, 0.0, inter / union)
 
 
+def get_giou(bbox1: torch.Tensor, bbox2: torch.Tensor) -> torch.Tensor:
+    """eval.py:68-83: pairwise GIoU = IoU - (C - union)/C with C the area of the
+    smallest enclosing box; -1 where C == 0."""
+    a1 = get_area(bbox1)
+    a2 = get_area(bbox2)
+    inter = get_intersection_area(bbox1, bbox2)
+    union = a1[:, None] + a2[None, :] - inter
+    l = torch.minimum(bbox1[:, 0][:, None], bbox2[:, 0][None, :])
+    t = torch.minimum(bbox1[:, 1][:, None], bbox2[:, 1][None, :])
+    r = torch.maximum(bbox1[:, 2][:, None], bbox2[:, 2][None, :])
+    b = torch.maximum(bbox1[:, 3][:, None], bbox2[:, 3][None, :])
+    c = torch.clip(r - l, min=0) * torch.clip(b - t, min=0)
+    iou = torch.where(union == 0, 0, inter / union)
+    return torch.where(c == 0, -1, iou - ((c - union) / c))
+
+
 def iou_elementwise(ltrb1: torch.Tensor, ltrb2: torch.Tensor) -> torch.Tensor:
     """Same arithmetic and operation order as get_iou (eval.py:61-65), applied
     to broadcast-compatible (..., 4) tensors instead of all pairs (repair R3)."""

@@ -35,6 +35,10 @@ YH_MODE_DENSE = 1
 
 YH_MAX_CANDIDATES = 1024
 
+YH_BOX_IOU = 0
+YH_BOX_GIOU = 1
+YH_BOX_INTERSECTION = 2
+
 # name -> (restype, argtypes); mirrors include/yolo_head.h declaration by declaration
 SIGNATURES = {
     "yh_version": (c_int, []),
@@ -49,6 +53,8 @@ SIGNATURES = {
     "yh_loss_finalize": (c_int, [c_void_p, c_size_t, c_int64, c_int, c_float, c_void_p, c_void_p,
                                  c_int, c_void_p, c_void_p]),
     "yh_scale_grad": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "yh_pairwise_boxes": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "yh_box_area": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "yh_encode_targets": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "yh_decode_grid": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

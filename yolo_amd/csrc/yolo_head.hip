@@ -12,6 +12,7 @@
 #include "loss_kernels.hpp"
 #include "nms_kernels.hpp"
 #include "target_kernels.hpp"
+#include "box_kernels.hpp"
 
 namespace {
 
@@ -207,6 +208,32 @@ int yh_scale_grad(float* grad, const float* scale, int64_t n, void* stream) {
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(yh::scale_grad_kernel, dim3((unsigned)blocks), dim3(256), 0,
                        (hipStream_t)stream, grad, scale, (long long)n);
+    return launch_status();
+}
+
+int yh_pairwise_boxes(const float* ltrb1, const float* ltrb2, float* out, int64_t N, int64_t M,
+                      int kind, void* stream) {
+    if (N < 0 || M < 0 || N > ((int64_t)1 << 31) || M > ((int64_t)1 << 31)) return YH_ERR_SHAPE;
+    if (kind != YH_BOX_IOU && kind != YH_BOX_GIOU && kind != YH_BOX_INTERSECTION) return YH_ERR_ARG;
+    if (N == 0 || M == 0) return YH_OK;
+    if (!ltrb1 || !ltrb2 || !out) return YH_ERR_NULL;
+    if (!aligned(ltrb1, 16) || !aligned(ltrb2, 16) || !aligned(out, 4)) return YH_ERR_ALIGN;
+    int64_t blocks = (N * M + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(yh::pairwise_boxes_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, ltrb1, ltrb2, out, (long long)N, (long long)M, kind);
+    return launch_status();
+}
+
+int yh_box_area(const float* ltrb, float* out, int64_t n, void* stream) {
+    if (n < 0) return YH_ERR_SHAPE;
+    if (n == 0) return YH_OK;
+    if (!ltrb || !out) return YH_ERR_NULL;
+    if (!aligned(ltrb, 16) || !aligned(out, 4)) return YH_ERR_ALIGN;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(yh::box_area_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, ltrb, out, (long long)n);
     return launch_status();
 }
 
