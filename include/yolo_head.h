@@ -55,6 +55,7 @@ extern "C" {
 #define YH_OP_DECODE_NMS 1
 #define YH_OP_DECODE_GRID 2
 #define YH_OP_NMS 3
+#define YH_OP_MAP 4 /* batch = number of predictions */
 
 /* candidate modes of the NMS entry points */
 #define YH_MODE_REFERENCE 0 /* per cell the higher-confidence predictor (model.py:384-390) */
@@ -134,6 +135,24 @@ int yh_scale_grad(float* grad, const float* scale, int64_t n, void* stream);
 int yh_pairwise_boxes(const float* ltrb1, const float* ltrb2, float* out, int64_t N, int64_t M,
                       int kind, void* stream);
 int yh_box_area(const float* ltrb, float* out, int64_t n, void* stream);
+
+/*
+ * 11-point mean average precision exactly as eval.get_map / get_ap /
+ * get_accum_prec_and_recall compute it (eval.py:86-149), quirks included: IoU is
+ * multiplied by 8 before it meets the threshold (eval.py:99); a prediction is a
+ * true positive when ANY ground truth of its class reaches the threshold (the
+ * matched flags of eval.py:109-110 are never set); precision counts the
+ * predictions of every class (eval.py:124); recall divides by ALL ground truths
+ * (eval.py:125).  Predictions are ranked by confidence descending, equal
+ * confidences by lower index (torch.argsort leaves ties unspecified).
+ *   pred (P, 6) rows l,t,r,b,conf,class (the rows yh_decode_nms writes);
+ *   gt (G, 5) rows l,t,r,b,class; P <= 16384.
+ *   ap_out (n_classes) float64, map_out (1) float64 (eval.py:142, :149).
+ *   workspace: yh_workspace_bytes(YH_OP_MAP, P, 0, 0, 0) bytes.
+ */
+int yh_map_11point(const float* pred, const float* gt, int64_t P, int64_t G, int n_classes,
+                   float iou_thresh, double* ap_out, double* map_out, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 /*
  * Target encoder: ground-truth boxes -> the three loss inputs, on the device.

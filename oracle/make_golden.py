@@ -21,6 +21,7 @@ Fixtures (inputs AND the reference's outputs; data only):
   g6_terms.npz      reference get_coordinate_loss / get_classification_loss /
                     get_confidence_loss / get_loss run with documented patches
                     (see below): the composition lines are the reference's own
+  g8_map.npz        eval.get_map / get_ap (11-point mAP, quirks included)
   g7_oracle_cfg1.npz  NOT from the reference: the oracle's own outputs at
                     config 1 (batch 16), kept as a regression vector and as the
                     input/expected pair the GPU tests replay.
@@ -195,6 +196,37 @@ def main():
              gt_cls_prob=gc.numpy(), obj_mask=om.numpy(), resp_mask=resp.numpy(),
              coord=ref_coord.numpy(), cls=ref_cls.numpy(), conf=ref_conf.numpy(),
              loss=ref_total.numpy())
+
+    # ---- G8: 11-point mAP straight from eval.get_map / get_ap -------------------
+    cases = {}
+    gen = torch.Generator().manual_seed(108)
+    # case a: the shape of the reference's own scratch block (eval.py:152-173)
+    gt_a = torch.cat([torch.randint(0, 64, (32, 4), generator=gen),
+                      torch.randint(0, 10, (32, 1), generator=gen)], dim=1)
+    pr_a = torch.cat([torch.randint(0, 64, (1024, 4), generator=gen),
+                      torch.rand(1024, 1, generator=gen),
+                      torch.randint(0, 10, (1024, 1), generator=gen)], dim=1)
+    cases["a"] = (pr_a, gt_a.float(), 10, 0.5)
+    # case b: proper float boxes, 20 classes, predictions jittered around the ground truth
+    gt_box = _boxes(gen, 24, img=447.0)
+    gt_b = torch.cat([gt_box, torch.randint(0, 20, (24, 1), generator=gen).float()], dim=1)
+    src = torch.randint(0, 24, (300,), generator=gen)
+    pb = gt_box[src] + torch.randn(300, 4, generator=gen) * 12
+    pc = torch.where(torch.rand(300, generator=gen) < 0.7, gt_b[src, 4],
+                     torch.randint(0, 20, (300,), generator=gen).float())
+    pr_b = torch.cat([pb, torch.rand(300, 1, generator=gen), pc[:, None]], dim=1)
+    cases["b"] = (pr_b, gt_b, 20, 4.0)          # 8 * IoU >= 4.0  <=>  IoU >= 0.5
+    cases["c"] = (pr_b[:7], gt_b[:3], 20, 2.0)
+    g8 = {}
+    for k, (pr, gt_, ncls, thr) in cases.items():
+        g8[f"pred_{k}"] = pr.numpy()
+        g8[f"gt_{k}"] = gt_.numpy()
+        g8[f"ncls_{k}"] = ncls
+        g8[f"thr_{k}"] = thr
+        g8[f"map_{k}"] = np.float64(ref_eval.get_map(pred=pr, gt=gt_, n_classes=ncls, iou_thresh=thr))
+        g8[f"ap_{k}"] = np.array([ref_eval.get_ap(pred=pr, gt=gt_, cls_idx=c, iou_thresh=thr)
+                                  for c in range(ncls)], dtype=np.float64)
+    np.savez(os.path.join(OUT, "g8_map.npz"), **g8)
 
     # ---- G7: oracle regression vector at config 1 (NOT reference output) ----
     res = ref_cpu.loss_and_grad(pred, gx, gc, om)

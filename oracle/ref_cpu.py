@@ -421,3 +421,49 @@ def postprocess(out, conf_thresh, iou_thresh, mode=0, **hp):
     ltrb, score, cls, present = decode_candidates(out, mode, **hp)
     return nms_batch(ltrb.numpy(), score.numpy(), cls.numpy(), present.numpy(),
                      conf_thresh, iou_thresh)
+
+
+# ----------------------------------------------------------------------------
+# 11-point mAP -- eval.py:86-149, quirks included
+# ----------------------------------------------------------------------------
+def true_positive_flags(pred, gt, iou_thresh):
+    """What eval.py:96-119 computes, for all classes at once.  A prediction is a
+    true positive of ITS class when any ground truth of that class has
+    8 * IoU >= iou_thresh (the stray ``iou *= 8`` of eval.py:99 is kept; the
+    matched flags of eval.py:109-110 are never set, so matching is not one-to-one)."""
+    pred = torch.as_tensor(pred, dtype=torch.float32)
+    gt = torch.as_tensor(gt, dtype=torch.float32)
+    iou = get_iou(gt[:, :4], pred[:, :4])
+    iou *= 8
+    same = gt[:, 4][:, None] == pred[:, 5][None, :]
+    return (same & (iou >= iou_thresh)).any(dim=0).numpy()
+
+
+def get_ap(pred, gt, cls_idx, iou_thresh, tp=None):
+    """eval.py:121-142 for one class: precision counts every prediction of every
+    class (eval.py:124), recall divides by ALL ground truths (eval.py:125)."""
+    pred = torch.as_tensor(pred, dtype=torch.float32)
+    gt = torch.as_tensor(gt, dtype=torch.float32)
+    if tp is None:
+        tp = true_positive_flags(pred, gt, iou_thresh)
+    is_true = tp & (pred[:, 5].numpy() == cls_idx)
+    # ties in confidence: the lower index first (torch.argsort leaves them unspecified)
+    order = np.lexsort((np.arange(pred.shape[0]), -pred[:, 4].numpy().astype(np.float64)))
+    accum_tp = np.cumsum(is_true[order])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        accum_prec = accum_tp / np.arange(1, pred.shape[0] + 1)
+        accum_recall = accum_tp / gt.shape[0]
+    precs = []
+    for recall in np.linspace(0, 1, 11):
+        sel = accum_prec[accum_recall >= recall]
+        precs.append(0 if not np.any(sel) else sel.max())
+    return np.sum(precs) / 11
+
+
+def get_map(pred, gt, n_classes, iou_thresh=0.5):
+    """eval.py:145-149."""
+    tp = true_positive_flags(pred, gt, iou_thresh)
+    sum_ap = 0
+    for cls_idx in range(n_classes):
+        sum_ap += get_ap(pred, gt, cls_idx, iou_thresh, tp)
+    return sum_ap / n_classes

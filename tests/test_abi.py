@@ -16,7 +16,7 @@ HEADER = os.path.join(ROOT, "include", "yolo_head.h")
 def declared_functions():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(yh_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(yh_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():

@@ -1,0 +1,71 @@
+"""11-point mAP (eval.py:86-149): the oracle and the HIP kernels against values
+produced by the reference's own get_map / get_ap (golden g8), bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu
+
+
+def cases(golden):
+    g = golden("g8_map.npz")
+    for k in "abc":
+        yield (k, g[f"pred_{k}"], g[f"gt_{k}"], int(g[f"ncls_{k}"]), float(g[f"thr_{k}"]),
+               float(g[f"map_{k}"]), g[f"ap_{k}"])
+
+
+def test_oracle_map_equals_reference(golden):
+    for k, pred, gt, ncls, thr, want_map, want_ap in cases(golden):
+        assert ref_cpu.get_map(pred, gt, ncls, thr) == want_map, k
+        got = np.array([ref_cpu.get_ap(pred, gt, c, thr) for c in range(ncls)])
+        np.testing.assert_array_equal(got, want_ap)
+    assert any(m > 0 for _, _, _, _, _, m, _ in cases(golden))
+
+
+@pytest.mark.gpu
+def test_gpu_map_equals_reference(dev, golden):
+    from yolo_amd import box_ops
+
+    for k, pred, gt, ncls, thr, want_map, want_ap in cases(golden):
+        p, g = torch.from_numpy(pred).float().to(dev), torch.from_numpy(gt).float().to(dev)
+        ap, m = box_ops._map(p, g, ncls, thr)
+        np.testing.assert_array_equal(ap.cpu().numpy(), want_ap)        # float64, bit for bit
+        assert m.item() == want_map, k
+        assert box_ops.get_map(p, g, ncls, thr).item() == want_map
+        assert box_ops.get_ap(p, g, 3, thr, ncls).item() == want_ap[3]
+
+
+@pytest.mark.gpu
+def test_gpu_map_edge_cases_and_pipeline(dev):
+    from yolo_amd import MODE_REFERENCE, YOLOv1Head, box_ops, synth
+
+    # no predictions / no ground truth -> 0, as the reference's arithmetic gives
+    z6, z5 = torch.zeros(0, 6, device=dev), torch.zeros(0, 5, device=dev)
+    one = torch.tensor([[0., 0., 10., 10., .9, 1.]], device=dev)
+    assert box_ops.get_map(z6, torch.tensor([[0., 0., 10., 10., 1.]], device=dev), 3).item() == 0.0
+    assert box_ops.get_map(one, z5, 3).item() == 0.0
+    g1 = torch.tensor([[0., 0., 10., 10., 1.]])
+    assert box_ops.get_map(one, g1.to(dev), 3).item() == ref_cpu.get_map(one.cpu(), g1, 3)
+    # detections straight from the NMS kernel feed the metric (eval.py:89-94 row layouts)
+    head = YOLOv1Head()
+    pred = synth.make_pred(1, seed=5).to(dev)
+    dets, count = head.postprocess(pred, 0.3, 0.5, MODE_REFERENCE)
+    d = dets[0, : int(count[0])].contiguous()
+    ltrb, label, cnt = synth.make_gt_boxes(1, seed=6)
+    gt = torch.cat([ltrb[0, : int(cnt[0])], label[0, : int(cnt[0]), None].float()], dim=1)
+    got = box_ops.get_map(d, gt.to(dev), 20, 0.5).item()
+    assert got == ref_cpu.get_map(d.cpu(), gt, 20, 0.5)
+    # larger random problem against the oracle
+    gen = torch.Generator().manual_seed(3)
+    P, G = 3000, 150
+    gb = torch.rand(G, 2, generator=gen) * 300
+    gtl = torch.cat([gb, gb + 20 + torch.rand(G, 2, generator=gen) * 100,
+                     torch.randint(0, 20, (G, 1), generator=gen).float()], dim=1)
+    src = torch.randint(0, G, (P,), generator=gen)
+    pl = torch.cat([gtl[src, :4] + torch.randn(P, 4, generator=gen) * 8, torch.rand(P, 1, generator=gen),
+                    torch.where(torch.rand(P, 1, generator=gen) < 0.6, gtl[src, 4:5],
+                                torch.randint(0, 20, (P, 1), generator=gen).float())], dim=1)
+    pl[10, 4] = pl[20, 4]                                        # a confidence tie
+    assert box_ops.get_map(pl.to(dev), gtl.to(dev), 20, 4.0).item() == ref_cpu.get_map(pl, gtl, 20, 4.0)
+    with pytest.raises(Exception):
+        box_ops.get_map(torch.zeros(20000, 6, device=dev), gtl.to(dev), 20)

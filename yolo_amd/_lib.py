@@ -29,6 +29,7 @@ YH_OP_LOSS = 0
 YH_OP_DECODE_NMS = 1
 YH_OP_DECODE_GRID = 2
 YH_OP_NMS = 3
+YH_OP_MAP = 4
 
 YH_MODE_REFERENCE = 0
 YH_MODE_DENSE = 1
@@ -55,6 +56,8 @@ SIGNATURES = {
     "yh_scale_grad": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "yh_pairwise_boxes": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "yh_box_area": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "yh_map_11point": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p,
+                               c_void_p, c_void_p, c_size_t, c_void_p]),
     "yh_encode_targets": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "yh_decode_grid": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

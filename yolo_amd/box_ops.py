@@ -1,7 +1,8 @@
 """Pairwise box geometry on the GPU with the names and shapes of the reference's
 eval.py: get_area (eval.py:22-32), get_intersection_area (:35-50), get_iou
 (:53-65), get_giou (:68-83).  fp32 results are bit-identical to the reference's
-PyTorch expressions."""
+PyTorch expressions.  get_ap / get_map (eval.py:129-149) return float64 device
+tensors that equal the reference's numpy results."""
 from __future__ import annotations
 
 import torch
@@ -53,3 +54,34 @@ def get_iou(ltrb1, ltrb2):
 def get_giou(bbox1, bbox2):
     """eval.py:76-83: (N, 4), (M, 4) -> (N, M); -1 where the enclosing box is empty."""
     return _pairwise(bbox1, bbox2, _lib.YH_BOX_GIOU)
+
+
+def _map(pred, gt, n_classes, iou_thresh):
+    _need(pred, "pred", torch.float32)
+    _need(gt, "gt", torch.float32)
+    if pred.dim() != 2 or pred.shape[1] != 6:
+        raise ValueError(f"pred: expected shape (P, 6), got {tuple(pred.shape)}")      # eval.py:94
+    if gt.dim() != 2 or gt.shape[1] != 5:
+        raise ValueError(f"gt: expected shape (G, 5), got {tuple(gt.shape)}")          # eval.py:93
+    dev = pred.device
+    lib = _lib.load()
+    p, g = pred.shape[0], gt.shape[0]
+    ws = torch.empty(lib.yh_workspace_bytes(_lib.YH_OP_MAP, p, 0, 0, 0), dtype=torch.uint8, device=dev)
+    ap = torch.empty(int(n_classes), dtype=torch.float64, device=dev)
+    m = torch.empty((), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.yh_map_11point(pred.data_ptr(), gt.data_ptr(), p, g, int(n_classes),
+                                      float(iou_thresh), ap.data_ptr(), m.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), _stream(dev)))
+    return ap, m
+
+
+def get_ap(pred, gt, cls_idx, iou_thresh, n_classes=None):
+    """eval.py:129-142 for one class (0-d float64 tensor)."""
+    ap, _ = _map(pred, gt, (cls_idx + 1) if n_classes is None else n_classes, iou_thresh)
+    return ap[cls_idx]
+
+
+def get_map(pred, gt, n_classes, iou_thresh=0.5):
+    """eval.py:145-149: pred (P, 6) rows l,t,r,b,conf,class; gt (G, 5) rows l,t,r,b,class."""
+    return _map(pred, gt, n_classes, iou_thresh)[1]
