@@ -1,5 +1,6 @@
-// Pairwise box geometry of eval.py:22-83 (area, intersection, IoU, GIoU), one
-// lane per (i, j) pair with j fastest so the (N, M) result is written coalesced.
+// Pairwise box geometry of eval.py:22-83 (area, intersection, IoU, GIoU): a
+// workgroup owns part of one row i, lanes run over the columns j, so the (N, M)
+// result is written coalesced and no index division is needed.
 #pragma once
 #include "head_math.hpp"
 
@@ -7,36 +8,41 @@ namespace yh {
 
 constexpr int BOX_IOU = 0, BOX_GIOU = 1, BOX_INTERSECTION = 2;
 
+// grid: x covers the columns j (grid-stride), y covers the rows i (grid-stride);
+// row i's box is uniform across the workgroup
 __global__ __launch_bounds__(256) void pairwise_boxes_kernel(const float* __restrict__ ltrb1,
                                                              const float* __restrict__ ltrb2,
                                                              float* __restrict__ out, long long N,
                                                              long long M, int kind) {
-    const long long total = N * M;
-    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total;
-         g += (long long)gridDim.x * blockDim.x) {
-        const long long i = g / M, j = g - i * M;
+    for (long long i = blockIdx.y; i < N; i += gridDim.y) {
         const float4 a = reinterpret_cast<const float4*>(ltrb1)[i];
-        const float4 b = reinterpret_cast<const float4*>(ltrb2)[j];
-        const Box p = {a.x, a.y, a.z, a.w}, q = {b.x, b.y, b.z, b.w};
-        // get_intersection_area (eval.py:46-50)
-        const float iw = fmaxf(fminf(p.r, q.r) - fmaxf(p.l, q.l), 0.0f);
-        const float ih = fmaxf(fminf(p.b, q.b) - fmaxf(p.t, q.t), 0.0f);
-        const float inter = iw * ih;
-        float r = inter;
-        if (kind != BOX_INTERSECTION) {
-            // get_iou (eval.py:61-65)
-            const float uni = (box_area(p) + box_area(q)) - inter;
-            const float iou = uni == 0.0f ? 0.0f : inter / uni;
-            r = iou;
-            if (kind == BOX_GIOU) {
-                // get_smallest_enclosing_area and get_giou (eval.py:68-83)
-                const float cw = fmaxf(fmaxf(p.r, q.r) - fminf(p.l, q.l), 0.0f);
-                const float ch = fmaxf(fmaxf(p.b, q.b) - fminf(p.t, q.t), 0.0f);
-                const float c = cw * ch;
-                r = c == 0.0f ? -1.0f : iou - ((c - uni) / c);
+        const Box p = {a.x, a.y, a.z, a.w};
+        const float ap = box_area(p);
+        float* row = out + i * M;
+        for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < M;
+             j += (long long)gridDim.x * blockDim.x) {
+            const float4 b = reinterpret_cast<const float4*>(ltrb2)[j];
+            const Box q = {b.x, b.y, b.z, b.w};
+            // get_intersection_area (eval.py:46-50)
+            const float iw = fmaxf(fminf(p.r, q.r) - fmaxf(p.l, q.l), 0.0f);
+            const float ih = fmaxf(fminf(p.b, q.b) - fmaxf(p.t, q.t), 0.0f);
+            const float inter = iw * ih;
+            float r = inter;
+            if (kind != BOX_INTERSECTION) {
+                // get_iou (eval.py:61-65)
+                const float uni = (ap + box_area(q)) - inter;
+                const float iou = uni == 0.0f ? 0.0f : inter / uni;
+                r = iou;
+                if (kind == BOX_GIOU) {
+                    // get_smallest_enclosing_area and get_giou (eval.py:68-83)
+                    const float cw = fmaxf(fmaxf(p.r, q.r) - fminf(p.l, q.l), 0.0f);
+                    const float ch = fmaxf(fmaxf(p.b, q.b) - fminf(p.t, q.t), 0.0f);
+                    const float c = cw * ch;
+                    r = c == 0.0f ? -1.0f : iou - ((c - uni) / c);
+                }
             }
+            row[j] = r;
         }
-        out[g] = r;
     }
 }
 

@@ -220,9 +220,11 @@ int yh_pairwise_boxes(const float* ltrb1, const float* ltrb2, float* out, int64_
     if (N == 0 || M == 0) return YH_OK;
     if (!ltrb1 || !ltrb2 || !out) return YH_ERR_NULL;
     if (!aligned(ltrb1, 16) || !aligned(ltrb2, 16) || !aligned(out, 4)) return YH_ERR_ALIGN;
-    int64_t blocks = (N * M + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(yh::pairwise_boxes_kernel, dim3((unsigned)blocks), dim3(256), 0,
+    int64_t bx = (M + 255) / 256;
+    if (bx > 64) bx = 64;
+    int64_t by = 4096 / bx;   // about 4096 workgroups in all; each loops over its share of the rows
+    if (by > N) by = N;
+    hipLaunchKernelGGL(yh::pairwise_boxes_kernel, dim3((unsigned)bx, (unsigned)by), dim3(256), 0,
                        (hipStream_t)stream, ltrb1, ltrb2, out, (long long)N, (long long)M, kind);
     return launch_status();
 }
