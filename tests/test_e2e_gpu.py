@@ -1,0 +1,66 @@
+"""End-to-end training step at VOC shape: 448x448 synthetic images through a
+PyTorch-ROCm convolutional backbone (reduced width) and the HIP head; the
+reference's call sequence of train.py:84-94, with and without GradScaler."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "examples"))
+
+from oracle import ref_cpu
+from yolo_amd import YOLOv1Head, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_training_steps_reduce_the_loss(dev):
+    from train_step import make_backbone
+
+    torch.manual_seed(0)
+    net = make_backbone(width=0.125).to(dev)
+    head = YOLOv1Head(backbone=net)
+    optim = torch.optim.AdamW(net.parameters(), lr=3e-4)
+    image = torch.randn(4, 3, 448, 448, device=dev)
+    _, gx, gc, om = (t.to(dev) for t in synth.make_inputs(4, seed=0))
+    net.eval()                                           # dropout off: the loss must go down
+    losses = []
+    for _ in range(8):
+        loss = head.get_loss(image, gx, gc, om)          # train.py:84
+        optim.zero_grad()
+        loss.backward()                                  # train.py:93
+        optim.step()
+        losses.append(loss.item())
+    assert all(torch.isfinite(torch.tensor(losses)))
+    assert losses[-1] < losses[0]
+    # the head's loss equals the oracle's on the backbone output
+    with torch.no_grad():
+        out = head(image)
+        got = head.get_loss(image, gx, gc, om).item()
+    want = ref_cpu.get_loss(out.cpu(), gx.cpu(), gc.cpu(), om.cpu()).item()
+    assert abs(got - want) <= 1e-5 * abs(want)
+
+
+def test_grad_scaler_sequence(dev):
+    """scaler.scale(loss).backward(); scaler.step(optim); scaler.update() -- train.py:88-91."""
+    from train_step import make_backbone
+
+    torch.manual_seed(1)
+    net = make_backbone(width=0.125).to(dev).eval()
+    head = YOLOv1Head(backbone=net)
+    optim = torch.optim.SGD(net.parameters(), lr=1e-3)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    image = torch.randn(2, 3, 448, 448, device=dev)
+    _, gx, gc, om = (t.to(dev) for t in synth.make_inputs(2, seed=3))
+    # reference gradient of the last layer's bias without scaling
+    head.get_loss(image, gx, gc, om).backward()
+    want = net[-1].bias.grad.clone()
+    optim.zero_grad()
+    loss = head.get_loss(image, gx, gc, om)
+    scaler.scale(loss).backward()
+    assert torch.allclose(net[-1].bias.grad, want * 1024.0, rtol=1e-6, atol=0)
+    scaler.step(optim)
+    scaler.update()
+    assert torch.isfinite(net[-1].bias).all()
