@@ -344,7 +344,7 @@ def main():
         result["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "loss_fwd_bwd_kernel<2,20>",
+            "kernel": "loss_fwd_bwd_kernel<7,2,20>",
             "algorithmic_bytes_per_launch": algo,
             "kernel_us": t_loss["back_to_back_us"],
         }
