@@ -38,3 +38,12 @@ def timeit(fn, reps=200):
 for what in ("loss", "nms", "both"):
     for ns in (1, 2, 4):
         print(f"{what:5s} split {ns}: {timeit(make(ns, what)):.2f} us/step")
+
+# loss and nms on separate streams, each split into `ns` batch slices (2*ns streams in all)
+def make_sep(ns):
+    runs = [make(ns, "loss"), make(ns, "nms")]
+    def run():
+        for r in runs: r()
+    return run
+for ns in (1, 2, 4):
+    print(f"loss||nms, {ns} slices each ({2 * ns} streams): {timeit(make_sep(ns)):.2f} us/step")

@@ -128,9 +128,10 @@ __device__ __forceinline__ void group_sync() {
     }
 }
 
-// SRC 0: candidates decoded from the head tensor (BX_CT, C_CT > 0: compile-time
-// predictor/class counts, 0: run-time); SRC 1: candidates loaded from memory.
-template <int NT, int ITEMS, int SRC, int BX_CT, int C_CT>
+// SRC 0: candidates decoded from the head tensor (S_CT, BX_CT, C_CT > 0: grid
+// size and predictor/class counts fixed at compile time, so every channel of a
+// cell is a constant offset; 0: run-time); SRC 1: candidates loaded from memory.
+template <int NT, int ITEMS, int SRC, int S_CT, int BX_CT, int C_CT>
 __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int IPB = NMS_BLOCK / NT;  // images per workgroup
@@ -142,10 +143,9 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
     const int lane = threadIdx.x & 63;
     const int wv = t >> 6;  // wavefront within the image group
     const long long img = (long long)blockIdx.x * IPB + sub;
-    const bool live_img = img < a.batch;
     // NT == 64: a whole wavefront leaves and no workgroup barrier is used below;
     // NT == 256: the grid has exactly one workgroup per image, so this never fires.
-    if (!live_img) return;
+    if (img >= a.batch) return;
 
     unsigned char* region = smem + (size_t)sub * a.region_bytes;
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(region + a.off_keys);
@@ -156,7 +156,8 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
     int* ccls = reinterpret_cast<int*>(region + a.off_ccls);
 
     const int nslot = a.nslot;
-    const int S2 = a.S * a.S;
+    const int S = S_CT > 0 ? S_CT : a.S;
+    const int S2 = S * S;
 
     // ---- phase A: candidates ---------------------------------------------------
     Box cbox[ITEMS];
@@ -198,12 +199,12 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
 #pragma unroll
                         for (int q = 1; q < BX_CT; ++q)
                             if (k == q) { lx = v[5 * q]; ly = v[5 * q + 1]; lw = v[5 * q + 2]; lh = v[5 * q + 3]; }
-                        cbox[e] = box_from_logits(lx, ly, lw, lh, cell, a.S, a.cellf, a.imgf);
+                        cbox[e] = box_from_logits(lx, ly, lw, lh, cell, S, a.cellf, a.imgf);
                         ccl[e] = cell_class(logit, 5 * BX_CT, C_CT);
                     } else {
                         const MemLogits logit{p, S2};
                         k = cell_best_conf(logit, nb, cb);
-                        cbox[e] = cell_box(logit, k, cell, a.S, a.cellf, a.imgf);
+                        cbox[e] = cell_box(logit, k, cell, S, a.cellf, a.imgf);
                         ccl[e] = cell_class_mem(p, 5 * nb, nc, S2);
                     }
                     cscore[e] = cb;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
                     const int k = n - cell * nb;
                     const float* p = pimg + cell + (5 * k) * S2;
                     const float lx = p[0], ly = p[S2], lw = p[2 * S2], lh = p[3 * S2], lc = p[4 * S2];
-                    cbox[e] = box_from_logits(lx, ly, lw, lh, cell, a.S, a.cellf, a.imgf);
+                    cbox[e] = box_from_logits(lx, ly, lw, lh, cell, S, a.cellf, a.imgf);
                     cscore[e] = sigmoidf_(lc);
                     ccl[e] = ccls[cell];
                     cidx[e] = n;
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
             const int n = e * NT + t;
-            if (n < nslot && live_img) {
+            if (n < nslot) {
                 const long long gi = img * nslot + n;
                 const float4 bx = reinterpret_cast<const float4*>(a.c_ltrb)[gi];
                 cbox[e] = {bx.x, bx.y, bx.z, bx.w};

@@ -66,7 +66,7 @@ void nms_layout(yh::NmsArgs& a, int slot_pad) {
     a.region_bytes = off;
 }
 
-template <int SRC, int BX_CT, int C_CT>
+template <int SRC, int S_CT, int BX_CT, int C_CT>
 int launch_nms_shape(yh::NmsArgs a, hipStream_t st) {
 #define YH_NMS_CASE(NT, ITEMS)                                                              \
     {                                                                                       \
@@ -74,7 +74,7 @@ int launch_nms_shape(yh::NmsArgs a, hipStream_t st) {
         const int ipb = yh::NMS_BLOCK / NT;                                                 \
         const unsigned grid = (unsigned)((a.batch + ipb - 1) / ipb);                        \
         const size_t lds = (size_t)a.region_bytes * ipb;                                    \
-        hipLaunchKernelGGL((yh::nms_kernel<NT, ITEMS, SRC, BX_CT, C_CT>), dim3(grid),       \
+        hipLaunchKernelGGL((yh::nms_kernel<NT, ITEMS, SRC, S_CT, BX_CT, C_CT>), dim3(grid), \
                            dim3(yh::NMS_BLOCK), lds, st, a);                                \
         return launch_status();                                                             \
     }
@@ -92,10 +92,10 @@ int launch_nms(const yh::NmsArgs& a, hipStream_t st) {
     if (a.nslot > YH_MAX_CANDIDATES || a.nout > YH_MAX_CANDIDATES) return YH_ERR_UNSUPPORTED;
     if constexpr (SRC == 0) {
         // the two shapes the head is benchmarked on get compile-time channel counts
-        if (a.nb == 2 && a.nc == 20) return launch_nms_shape<0, 2, 20>(a, st);
-        if (a.nb == 5 && a.nc == 80) return launch_nms_shape<0, 5, 80>(a, st);
+        if (a.S == 7 && a.nb == 2 && a.nc == 20) return launch_nms_shape<0, 7, 2, 20>(a, st);
+        if (a.S == 14 && a.nb == 5 && a.nc == 80) return launch_nms_shape<0, 14, 5, 80>(a, st);
     }
-    return launch_nms_shape<SRC, 0, 0>(a, st);
+    return launch_nms_shape<SRC, 0, 0, 0>(a, st);
 }
 
 }  // namespace
