@@ -63,6 +63,9 @@ def parse():
                     help="steps captured into one HIP graph (the remainder of --steps runs on a 1-step graph)")
     ap.add_argument("--prewarm-seconds", type=float, default=0.3,
                     help="untimed steps run before the warm-up so the GPU clocks are at steady state")
+    ap.add_argument("--loss-path", choices=("pipelined", "two-launch"), default="pipelined",
+                    help="pipelined: one launch per step, the loss sums reach the device log one "
+                         "step late; two-launch: gradient kernel + finalize kernel per step")
     ap.add_argument("--serial", action="store_true",
                     help="run the loss and decode+NMS halves of the step on one stream instead of two")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -175,23 +178,42 @@ def main():
     s_nms = s_loss if args.serial else torch.cuda.Stream(dev)
     keep = {}
 
+    # The loss half logs its sums on the device (nothing on the host reads them per
+    # step), so by default it is ONE launch per step: the gradient kernel's first
+    # workgroup adds the previous step's rows (`--loss-path two-launch`: gradient
+    # kernel + finalize kernel per step).
+    pipelined = args.loss_path == "pipelined"
+    if pipelined and spg % 2:
+        spg += 1                                   # the two workspace halves alternate
+        every = max(spg, (every // spg) * spg)
+        log = LossLog(dev, capacity=every)
+
     def loss_step():
-        keep["loss"] = head.loss_fwd_bwd(pred, gx, gc, om, global_batch=global_batch, log=log)
+        if pipelined:
+            keep["loss"] = head.loss_step_pipelined(pred, gx, gc, om, log, global_batch=global_batch)
+        else:
+            keep["loss"] = head.loss_fwd_bwd(pred, gx, gc, om, global_batch=global_batch, log=log)
+
+    def loss_flush():
+        if pipelined:
+            with torch.cuda.stream(s_loss):
+                head.flush_loss_log(log)
 
     def nms_step():
         keep["nms"] = head.postprocess(pred, CONF_T, IOU_T, MODE_REFERENCE)
 
     use_graph = not args.no_graph
     with torch.cuda.stream(s_loss):
-        for _ in range(3):
+        for _ in range(4):
             loss_step()
             nms_step()
+    loss_flush()
     torch.cuda.synchronize()
     graphs = {}
     if use_graph:
         try:
             for name, fn, st in (("loss", loss_step, s_loss), ("nms", nms_step, s_nms)):
-                for n in sorted({1, spg}):
+                for n in sorted({2 if pipelined else 1, spg}):
                     g = torch.cuda.CUDAGraph()
                     # thread_local: the process group's watchdog thread may touch the HIP
                     # runtime while this thread captures
@@ -214,11 +236,18 @@ def main():
                     graphs[("loss", spg)].replay()
                 with torch.cuda.stream(s_nms):
                     graphs[("nms", spg)].replay()
-            for _ in range(n % spg):
+            rest, unit = n % spg, 2 if pipelined else 1
+            for _ in range(rest // unit):
                 with torch.cuda.stream(s_loss):
-                    graphs[("loss", 1)].replay()
+                    graphs[("loss", unit)].replay()
                 with torch.cuda.stream(s_nms):
-                    graphs[("nms", 1)].replay()
+                    graphs[("nms", unit)].replay()
+            if rest % unit:                          # one odd step: eagerly, then restart the halves
+                with torch.cuda.stream(s_loss):
+                    loss_step()
+                with torch.cuda.stream(s_nms):
+                    nms_step()
+                loss_flush()
         else:
             for _ in range(n):
                 with torch.cuda.stream(s_loss):
@@ -240,6 +269,7 @@ def main():
         run_steps(spg * 8)
         torch.cuda.synchronize()
     run_steps(args.warmup)
+    loss_flush()
     torch.cuda.synchronize()
     log.reset()
 
@@ -251,6 +281,7 @@ def main():
     while done < args.steps:
         n = min(every, args.steps - done)
         run_steps(n)
+        loss_flush()                             # the step the pipelined path still holds back
         with torch.cuda.stream(s_loss):          # ordered after the loss kernels that filled the ring
             reducer.flush(log.ring, n)
         done += n
@@ -293,6 +324,9 @@ def main():
             "conf_thresh": CONF_T, "iou_thresh": IOU_T, "nms_mode": "reference",
             "parallelism": f"dp{world} by image, loss all-reduce every {every} steps",
             "launch": f"hip-graph, {spg} steps per graph" if use_graph else "eager",
+            "loss_path": "one launch per step, loss sums logged on the device one step late "
+                         "(yh_loss_fwd_bwd_pipelined)" if pipelined
+                         else "gradient kernel + finalize kernel per step",
             "streams": 1 if args.serial else 2,
         },
         "loss": loss_value,
@@ -310,11 +344,24 @@ def main():
         cnt = torch.empty(batch, dtype=torch.int32, device=dev)
         terms = torch.empty(5, device=dev)
 
+        wsp = torch.zeros(lib.yh_workspace_bytes(_lib.YH_OP_LOSS_PIPELINED, batch, S, BX, C),
+                          dtype=torch.uint8, device=dev)
+        klog = LossLog(dev, capacity=64)
+        phase = [0]
+
         def k_loss():
-            _lib.check(lib.yh_loss_partials(pred.data_ptr(), gx.data_ptr(), gc.data_ptr(),
-                                            om8.data_ptr(), grad.data_ptr(), ws.data_ptr(),
-                                            ws.numel(), batch, S, BX, C, IMG, 5.0, 0.5,
-                                            1.0 / global_batch, st))
+            if pipelined:       # the kernel the timed region ran
+                phase[0] ^= 1
+                _lib.check(lib.yh_loss_fwd_bwd_pipelined(
+                    pred.data_ptr(), gx.data_ptr(), gc.data_ptr(), om8.data_ptr(), grad.data_ptr(),
+                    None, klog.ring.data_ptr(), klog.capacity, klog.cursor.data_ptr(),
+                    wsp.data_ptr(), wsp.numel(), phase[0], batch, S, BX, C, IMG, 5.0, 0.5,
+                    1.0 / global_batch, st))
+            else:
+                _lib.check(lib.yh_loss_partials(pred.data_ptr(), gx.data_ptr(), gc.data_ptr(),
+                                                om8.data_ptr(), grad.data_ptr(), ws.data_ptr(),
+                                                ws.numel(), batch, S, BX, C, IMG, 5.0, 0.5,
+                                                1.0 / global_batch, st))
 
         def k_fin():
             _lib.check(lib.yh_loss_finalize(ws.data_ptr(), ws.numel(), batch, S, 1.0 / global_batch,
@@ -344,7 +391,7 @@ def main():
         result["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "loss_fwd_bwd_kernel<7,2,20>",
+            "kernel": "loss_fwd_bwd_kernel<7,2,20,%s>" % ("true" if pipelined else "false"),
             "algorithmic_bytes_per_launch": algo,
             "kernel_us": t_loss["back_to_back_us"],
         }

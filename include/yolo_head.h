@@ -56,6 +56,7 @@ extern "C" {
 #define YH_OP_DECODE_GRID 2
 #define YH_OP_NMS 3
 #define YH_OP_MAP 4 /* batch = number of predictions */
+#define YH_OP_LOSS_PIPELINED 5
 
 /* candidate modes of the NMS entry points */
 #define YH_MODE_REFERENCE 0 /* per cell the higher-confidence predictor (model.py:384-390) */
@@ -111,6 +112,37 @@ int yh_loss_partials(const float* pred, const float* gt_xywh, const float* gt_cl
 int yh_loss_finalize(const void* workspace, size_t workspace_bytes, int64_t batch, int S,
                      float inv_global_batch, float* loss_terms, float* log_ring,
                      int log_capacity, int32_t* log_cursor, void* stream);
+
+/*
+ * Pipelined loss step for training loops that only LOG the loss (the reference
+ * reads it once per step for its running mean, train.py:84-94): one launch per
+ * step.  The call writes grad_pred as yh_loss_fwd_bwd does and leaves its rows in
+ * half `phase` (0 or 1) of the workspace; its first workgroup meanwhile adds the
+ * rows the PREVIOUS call left in the other half -- bit for bit what
+ * yh_loss_finalize computes -- and writes them to loss_terms_prev[5] (may be
+ * NULL) and to the log ring (may be NULL).  So every step's sums reach the log,
+ * one call late, and no second kernel sits between two steps.
+ *
+ * Contract: alternate phase 0, 1, 0, ... from call to call on the same workspace
+ * pointer and size (a captured graph that is replayed needs an even number of
+ * steps).  yh_loss_pipelined_flush(workspace, size, phase of the LAST call, ...)
+ * logs the step that is still pending (a no-op if none is; the other half is
+ * looked at as well); call it before reading the log to the end, and whenever
+ * the alternation is to restart -- after it any phase may come first.
+ * workspace: yh_workspace_bytes(YH_OP_LOSS_PIPELINED, ...) bytes, 16-byte aligned,
+ * and -- unlike the other workspaces of this library -- its contents matter: clear
+ * it once with yh_loss_workspace_init (or any zero fill) before the first call.
+ * Calls that share a workspace must not overlap.  No counterpart in the reference.
+ */
+int yh_loss_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
+int yh_loss_fwd_bwd_pipelined(const float* pred, const float* gt_xywh, const float* gt_cls,
+                              const uint8_t* obj_mask, float* grad_pred, float* loss_terms_prev,
+                              float* log_ring, int log_capacity, int32_t* log_cursor,
+                              void* workspace, size_t workspace_bytes, int phase, int64_t batch,
+                              int S, int Bx, int C, int img_size, float lambda_coord,
+                              float lambda_noobj, float inv_global_batch, void* stream);
+int yh_loss_pipelined_flush(void* workspace, size_t workspace_bytes, int phase, float* loss_terms,
+                            float* log_ring, int log_capacity, int32_t* log_cursor, void* stream);
 
 /*
  * grad[i] *= *scale for i < n, in place; does not touch memory when *scale == 1.

@@ -283,3 +283,92 @@ def test_hip_graph_replay(dev):
     torch.cuda.synchronize()
     t2, g2 = head.loss_fwd_bwd(pred2, gx, gc, om)
     assert torch.equal(terms, t2) and torch.equal(grad, g2)
+
+
+def test_pipelined_step_logs_every_step_one_call_late(dev):
+    """yh_loss_fwd_bwd_pipelined: same gradient bits as the two-launch path, and the
+    log ring ends up with the same rows (bit for bit) as yh_loss_finalize writes --
+    for batch sizes that change from call to call, including an empty batch."""
+    from yolo_amd import LossLog
+    head, ref_head = YOLOv1Head(), YOLOv1Head()
+    log, ref_log = LossLog(dev, capacity=16), LossLog(dev, capacity=16)
+    prev = torch.full((5,), float("nan"), device=dev)
+    want_terms = []
+    for i, batch in enumerate((64, 5, 4096, 0, 1, 37, 4096, 300, 6)):
+        pred, gx, gc, om = (x.to(dev) for x in synth.make_inputs(batch, seed=200 + i))
+        grad = head.loss_step_pipelined(pred, gx, gc, om, log, terms_prev=prev)
+        terms, ref_grad = ref_head.loss_fwd_bwd(pred, gx, gc, om, log=ref_log)
+        assert torch.equal(grad, ref_grad)
+        torch.cuda.synchronize()
+        assert int(log.cursor.item()) == i            # one call late
+        if i:
+            assert torch.equal(prev, want_terms[-1])
+        want_terms.append(terms.clone())
+    head.flush_loss_log(log, terms=prev)
+    head.flush_loss_log(log)                          # nothing pending any more: no-op
+    torch.cuda.synchronize()
+    assert int(log.cursor.item()) == 9 == int(ref_log.cursor.item())
+    assert torch.equal(log.ring, ref_log.ring)
+    assert torch.equal(prev, want_terms[-1])
+
+
+def test_pipelined_step_in_a_replayed_graph(dev):
+    from yolo_amd import LossLog
+    head, ref_head = YOLOv1Head(), YOLOv1Head()
+    log = LossLog(dev, capacity=64)
+    sets = [tuple(x.to(dev) for x in synth.make_inputs(257, seed=300 + i)) for i in range(2)]
+    want = [ref_head.loss_fwd_bwd(*s)[0][:4].clone() for s in sets]
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):                      # warm-up outside the capture
+        head.loss_step_pipelined(*sets[0], log)
+        head.loss_step_pipelined(*sets[1], log)
+        head.flush_loss_log(log)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    log.reset()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for k in range(4):                             # an even number of steps
+            head.loss_step_pipelined(*sets[k % 2], log)
+    for _ in range(3):
+        g.replay()
+    head.flush_loss_log(log)
+    torch.cuda.synchronize()
+    assert int(log.cursor.item()) == 12
+    for i in range(12):
+        assert torch.equal(log.ring[i], want[i % 2])
+
+
+def test_pipelined_other_shape_and_errors(dev):
+    from yolo_amd import _lib, LossLog
+    lib = _lib.load()
+    head = YOLOv1Head(img_size=320, n_cells=5, n_bboxes=3, n_classes=7)
+    ref_head = YOLOv1Head(img_size=320, n_cells=5, n_bboxes=3, n_classes=7)
+    log, ref_log = LossLog(dev, 8), LossLog(dev, 8)
+    for i in range(3):
+        pred, gx, gc, om = (x.to(dev) for x in synth.make_inputs(33 + i, 5, 3, 7, 320, seed=8 + i))
+        grad = head.loss_step_pipelined(pred, gx, gc, om, log)
+        _, ref_grad = ref_head.loss_fwd_bwd(pred, gx, gc, om, log=ref_log)
+        assert torch.equal(grad, ref_grad)
+    head.flush_loss_log(log)
+    torch.cuda.synchronize()
+    assert torch.equal(log.ring, ref_log.ring)
+    st = torch.cuda.current_stream().cuda_stream
+    om8 = om.view(torch.uint8)
+    ws = torch.zeros(lib.yh_workspace_bytes(_lib.YH_OP_LOSS_PIPELINED, 35, 5, 3, 7), dtype=torch.uint8, device=dev)
+
+    def call(ws_ptr=ws.data_ptr(), ws_bytes=ws.numel(), phase=0, ring=log.ring.data_ptr(), cap=8,
+             cur=log.cursor.data_ptr()):
+        return lib.yh_loss_fwd_bwd_pipelined(pred.data_ptr(), gx.data_ptr(), gc.data_ptr(),
+                                             om8.data_ptr(), grad.data_ptr(), None, ring, cap, cur,
+                                             ws_ptr, ws_bytes, phase, 35, 5, 3, 7, 320, 5.0, 0.5,
+                                             1 / 35, st)
+    assert call(phase=2) == _lib.YH_ERR_ARG
+    assert call(ws_ptr=None) == _lib.YH_ERR_WORKSPACE
+    assert call(ws_bytes=ws.numel() // 2) == _lib.YH_ERR_WORKSPACE   # sized for one half only
+    assert call(cur=None) == _lib.YH_ERR_ARG
+    assert call(cap=0) == _lib.YH_ERR_ARG
+    assert lib.yh_loss_pipelined_flush(ws.data_ptr(), ws.numel(), 3, None, None, 0, None, st) == _lib.YH_ERR_ARG
+    assert lib.yh_loss_workspace_init(None, 64, st) == _lib.YH_ERR_WORKSPACE
+    torch.cuda.synchronize()

@@ -30,6 +30,7 @@ YH_OP_DECODE_NMS = 1
 YH_OP_DECODE_GRID = 2
 YH_OP_NMS = 3
 YH_OP_MAP = 4
+YH_OP_LOSS_PIPELINED = 5
 
 YH_MODE_REFERENCE = 0
 YH_MODE_DENSE = 1
@@ -53,6 +54,13 @@ SIGNATURES = {
                                  c_float, c_void_p]),
     "yh_loss_finalize": (c_int, [c_void_p, c_size_t, c_int64, c_int, c_float, c_void_p, c_void_p,
                                  c_int, c_void_p, c_void_p]),
+    "yh_loss_workspace_init": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "yh_loss_fwd_bwd_pipelined": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
+                                          c_int, c_int64, c_int, c_int, c_int, c_int, c_float,
+                                          c_float, c_float, c_void_p]),
+    "yh_loss_pipelined_flush": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_int,
+                                        c_void_p, c_void_p]),
     "yh_scale_grad": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "yh_pairwise_boxes": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "yh_box_area": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),

@@ -192,7 +192,7 @@ struct GlobalLogits {
 // wave -> workgroup reduction of the three partial sums in a fixed order; one
 // row of `partials` per workgroup
 __device__ __forceinline__ void loss_block_reduce(float acc_coord, float acc_conf, float acc_cls,
-                                                  float* __restrict__ partials) {
+                                                  float* __restrict__ partials, int row) {
     __shared__ float red[LOSS_THREADS / 64][3];
     acc_coord = wave_sum(acc_coord);
     acc_conf = wave_sum(acc_conf);
@@ -208,19 +208,126 @@ __device__ __forceinline__ void loss_block_reduce(float acc_coord, float acc_con
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < LOSS_THREADS / 64; ++w) s += red[w][threadIdx.x];
-        partials[(size_t)blockIdx.x * 4 + threadIdx.x] = s;
+        partials[(size_t)row * 4 + threadIdx.x] = s;
     }
 }
 
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Called by all LOSS_THREADS threads of one workgroup; see loss_finalize_kernel.
+// Four rows per thread are in flight per round trip.  loss_terms may be null.
+__device__ __forceinline__ void loss_sum_rows(const float* __restrict__ partials, int nrows,
+                                              float inv_gb, float* __restrict__ loss_terms,
+                                              float* __restrict__ log_ring, int log_capacity,
+                                              int* __restrict__ log_cursor) {
+    __shared__ double red64[LOSS_THREADS / 64][3];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    const float4* rows = reinterpret_cast<const float4*>(partials);
+    for (int r0 = threadIdx.x; r0 < nrows; r0 += 4 * LOSS_THREADS) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u * LOSS_THREADS;
+            v[u] = r < nrows ? rows[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a0 += (double)v[u].x;
+            a1 += (double)v[u].y;
+            a2 += (double)v[u].z;
+        }
+    }
+    a0 = wave_sum_f64(a0);
+    a1 = wave_sum_f64(a1);
+    a2 = wave_sum_f64(a2);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        red64[wave][0] = a0;
+        red64[wave][1] = a1;
+        red64[wave][2] = a2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double c = 0.0, f = 0.0, k = 0.0;
+#pragma unroll
+        for (int w = 0; w < LOSS_THREADS / 64; ++w) {
+            c += red64[w][0];
+            f += red64[w][1];
+            k += red64[w][2];
+        }
+        const double tot = (c + f) + k;
+        if (loss_terms) {
+            loss_terms[0] = (float)c;
+            loss_terms[1] = (float)f;
+            loss_terms[2] = (float)k;
+            loss_terms[3] = (float)tot;
+            loss_terms[4] = (float)(tot * (double)inv_gb);
+        }
+        if (log_ring) {
+            const int cur = *log_cursor;
+            float* row = log_ring + (size_t)(cur % log_capacity) * 4;
+            row[0] = (float)c;
+            row[1] = (float)f;
+            row[2] = (float)k;
+            row[3] = (float)tot;
+            *log_cursor = cur + 1;
+        }
+    }
+}
+
+// Pipelined loss step: a call leaves its rows in one half of the workspace and
+// its first workgroup adds the rows the PREVIOUS call left in the other half,
+// so no second kernel sits between two steps.  A half starts with a header:
+// word 0 = number of rows + 1 (0: nothing pending), word 1 = inv_gb of that call.
+struct LossPipe {
+    int* own_hdr;            // header of the half this call fills (null: flush only)
+    int* prev_hdr;           // header of the half the previous call filled
+    const float* prev_rows;
+    float* terms_prev;       // receives the previous call's five loss terms; may be null
+    float* log_ring;
+    int* log_cursor;
+    int log_capacity;
+};
+
+// Run by all threads of the logging workgroup.  Kernel boundaries order it after
+// the call that wrote the rows; nothing else in this launch touches either header.
+__device__ __forceinline__ void loss_pipe_log(const LossPipe& p, int own_rows, float own_inv_gb) {
+    if (p.own_hdr && threadIdx.x == 0) {
+        p.own_hdr[0] = own_rows + 1;
+        p.own_hdr[1] = __float_as_int(own_inv_gb);
+    }
+    const int pending = p.prev_hdr[0];
+    if (pending <= 0) return;
+    const float inv = __int_as_float(p.prev_hdr[1]);
+    loss_sum_rows(p.prev_rows, pending - 1, inv, p.terms_prev, p.log_ring, p.log_capacity,
+                  p.log_cursor);
+    if (threadIdx.x == 0) p.prev_hdr[0] = 0;   // consumed (after the barrier inside the sum)
+}
+
 // Run-time shape (any S, Bx, C within the limits): channels are read on use.
+template <bool PIPE>
 __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
     const float* __restrict__ pred, const float* __restrict__ gt_xywh,
     const float* __restrict__ gt_cls, const uint8_t* __restrict__ obj_mask,
     float* __restrict__ grad, float* __restrict__ partials, long long batch, int S, int nb,
-    int nc, int imgs_per_block, float cellf, float imgf, float lc, float ln, float inv_gb) {
+    int nc, int imgs_per_block, float cellf, float imgf, float lc, float ln, float inv_gb,
+    LossPipe pipe) {
+    int bid = blockIdx.x;
+    if constexpr (PIPE) {
+        // workgroup 0 logs the previous call, the others are this call's row 0, 1, ...
+        if (bid == 0) {
+            loss_pipe_log(pipe, (int)gridDim.x - 1, inv_gb);
+            return;
+        }
+        --bid;
+    }
     const int S2 = S * S;
     const long long D = 5 * nb + nc;
-    const long long img0 = (long long)blockIdx.x * imgs_per_block;
+    const long long img0 = (long long)bid * imgs_per_block;
     const int nitems = imgs_per_block * S2;
     float acc_coord = 0.f, acc_conf = 0.f, acc_cls = 0.f;
     for (int item = threadIdx.x; item < nitems; item += LOSS_THREADS) {
@@ -239,7 +346,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
                 loss_noobj_cell(logit, grad + off, S2, nb, nc, ln, inv_gb, acc_conf);
         }
     }
-    loss_block_reduce(acc_coord, acc_conf, acc_cls, partials);
+    loss_block_reduce(acc_coord, acc_conf, acc_cls, partials, bid);
 }
 
 // Compile-time shape.  Every lane fetches the D logits of its cell up front (one
@@ -249,15 +356,24 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
 // (Compacting the object cells of a workgroup into one wavefront through LDS was
 // measured slower here: the barriers and the single-wave object path lengthen
 // each workgroup's critical path more than the saved VALU work is worth.)
-template <int S, int BX, int C>
+template <int S, int BX, int C, bool PIPE>
 __global__ __launch_bounds__(LOSS_THREADS, 4) void loss_fwd_bwd_kernel(
     const float* __restrict__ pred, const float* __restrict__ gt_xywh,
     const float* __restrict__ gt_cls, const uint8_t* __restrict__ obj_mask,
     float* __restrict__ grad, float* __restrict__ partials, long long batch,
-    int imgs_per_block, float cellf, float imgf, float lc, float ln, float inv_gb) {
+    int imgs_per_block, float cellf, float imgf, float lc, float ln, float inv_gb,
+    LossPipe pipe) {
+    int bid = blockIdx.x;
+    if constexpr (PIPE) {
+        if (bid == 0) {
+            loss_pipe_log(pipe, (int)gridDim.x - 1, inv_gb);
+            return;
+        }
+        --bid;
+    }
     constexpr int D = 5 * BX + C;
     constexpr int S2 = S * S;
-    const long long img0 = (long long)blockIdx.x * imgs_per_block;
+    const long long img0 = (long long)bid * imgs_per_block;
     const int nitems = imgs_per_block * S2;
 
     float acc_coord = 0.f, acc_conf = 0.f, acc_cls = 0.f;
@@ -281,66 +397,28 @@ __global__ __launch_bounds__(LOSS_THREADS, 4) void loss_fwd_bwd_kernel(
                 loss_noobj_cell(logit, grad + off, S2, BX, C, ln, inv_gb, acc_conf);
         }
     }
-    loss_block_reduce(acc_coord, acc_conf, acc_cls, partials);
+    loss_block_reduce(acc_coord, acc_conf, acc_cls, partials, bid);
 }
 
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-constexpr int FINALIZE_THREADS = 1024;
-
-// Adds the per-workgroup rows in a fixed order (fp64 accumulation) and writes
-// coord, conf, class, total and total * inv_gb.  One row per thread in flight,
-// so the kernel costs one memory round trip; shuffles and one LDS hop reduce.
-__global__ __launch_bounds__(FINALIZE_THREADS) void loss_finalize_kernel(
+// One workgroup of LOSS_THREADS threads: adds the rows in a fixed order (fp64
+// accumulation) and writes coord, conf, class, total and total * inv_gb.  If
+// log_ring is given the four sums also go to row (*log_cursor % log_capacity) of
+// the device-side loss log and the cursor advances (it lives on the device, so a
+// replayed graph keeps logging).
+__global__ __launch_bounds__(LOSS_THREADS) void loss_finalize_kernel(
     const float* __restrict__ partials, int nrows, float inv_gb, float* __restrict__ loss_terms,
     float* __restrict__ log_ring, int log_capacity, int* __restrict__ log_cursor) {
-    __shared__ double red[FINALIZE_THREADS / 64][3];
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    for (int r = threadIdx.x; r < nrows; r += FINALIZE_THREADS) {
-        const float4 v = reinterpret_cast<const float4*>(partials)[r];
-        a0 += (double)v.x;
-        a1 += (double)v.y;
-        a2 += (double)v.z;
-    }
-    a0 = wave_sum_f64(a0);
-    a1 = wave_sum_f64(a1);
-    a2 = wave_sum_f64(a2);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) {
-        red[wave][0] = a0;
-        red[wave][1] = a1;
-        red[wave][2] = a2;
-    }
+    loss_sum_rows(partials, nrows, inv_gb, loss_terms, log_ring, log_capacity, log_cursor);
+}
+
+// The pipelined loss step on its own: logs what the last call left behind in its
+// half, then looks at the other half as well (at most one holds a pending step
+// when the phases alternated as documented).
+__global__ __launch_bounds__(LOSS_THREADS) void loss_pipe_flush_kernel(LossPipe last,
+                                                                       LossPipe other) {
+    loss_pipe_log(last, 0, 0.f);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double c = 0.0, f = 0.0, k = 0.0;
-#pragma unroll
-        for (int w = 0; w < FINALIZE_THREADS / 64; ++w) {
-            c += red[w][0];
-            f += red[w][1];
-            k += red[w][2];
-        }
-        const double tot = (c + f) + k;
-        loss_terms[0] = (float)c;
-        loss_terms[1] = (float)f;
-        loss_terms[2] = (float)k;
-        loss_terms[3] = (float)tot;
-        loss_terms[4] = (float)(tot * (double)inv_gb);
-        if (log_ring) {
-            // device-side loss log: the cursor survives graph replays
-            const int cur = *log_cursor;
-            float* row = log_ring + (size_t)(cur % log_capacity) * 4;
-            row[0] = (float)c;
-            row[1] = (float)f;
-            row[2] = (float)k;
-            row[3] = (float)tot;
-            *log_cursor = cur + 1;
-        }
-    }
+    loss_pipe_log(other, 0, 0.f);
 }
 
 // grad[i] *= *scale, skipped entirely when *scale == 1 (the loss.backward() case).

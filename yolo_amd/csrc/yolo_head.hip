@@ -124,10 +124,80 @@ const char* yh_strerror(int rc) {
 size_t yh_workspace_bytes(int op, int64_t batch, int S, int Bx, int C) {
     (void)Bx; (void)C;
     if (op == YH_OP_MAP) return batch < 1 ? 16 : (size_t)batch * sizeof(int);
-    if (op != YH_OP_LOSS || batch < 0 || S < 1 || S > YH_MAX_S) return 0;
+    if ((op != YH_OP_LOSS && op != YH_OP_LOSS_PIPELINED) || batch < 0 || S < 1 || S > YH_MAX_S)
+        return 0;
     const int64_t rows = loss_blocks(batch, S);
-    return (size_t)(rows < 1 ? 1 : rows) * 4 * sizeof(float);
+    const size_t bytes = (size_t)(rows < 1 ? 1 : rows) * 4 * sizeof(float);
+    // pipelined: two halves, each a 16-byte header and the rows
+    return op == YH_OP_LOSS_PIPELINED ? 2 * (16 + bytes) : bytes;
 }
+
+}  // extern "C"
+
+namespace {
+
+// Argument checks and launch shared by yh_loss_partials (pipe == nullptr, rows at
+// `rows_base`) and the pipelined step (workgroup 0 logs the previous call).
+int loss_launch(const float* pred, const float* gt_xywh, const float* gt_cls,
+                const uint8_t* obj_mask, float* grad_pred, float* rows_base, int64_t batch,
+                int S, int Bx, int C, int img_size, float lambda_coord, float lambda_noobj,
+                float inv_global_batch, const yh::LossPipe* pipe, hipStream_t st) {
+    if (batch > 0 && (!pred || !gt_xywh || !gt_cls || !obj_mask || !grad_pred)) return YH_ERR_NULL;
+    if (!aligned(gt_xywh, 16) || !aligned(pred, 4) || !aligned(grad_pred, 4) ||
+        !aligned(gt_cls, 4))
+        return YH_ERR_ALIGN;
+    if (isnan(lambda_coord) || isnan(lambda_noobj) || isnan(inv_global_batch)) return YH_ERR_ARG;
+
+    const int64_t rows = loss_blocks(batch, S);
+    if (rows == 0 && !pipe) return YH_OK;
+    const int g = loss_imgs_per_block(S);
+    const float cellf = (float)(img_size / S);
+    const float imgf = (float)img_size;
+    const bool fast = S == 7 && Bx == 2 && C == 20 && aligned(gt_cls, 16);
+    const yh::LossPipe pp = pipe ? *pipe : yh::LossPipe{};
+    const dim3 grid((unsigned)(rows + (pipe ? 1 : 0)));
+#define YH_LOSS_LAUNCH(PIPE)                                                                     \
+    if (fast)                                                                                    \
+        hipLaunchKernelGGL((yh::loss_fwd_bwd_kernel<7, 2, 20, PIPE>), grid,                      \
+                           dim3(yh::LOSS_THREADS), 0, st, pred, gt_xywh, gt_cls, obj_mask,       \
+                           grad_pred, rows_base, (long long)batch, g, cellf, imgf, lambda_coord, \
+                           lambda_noobj, inv_global_batch, pp);                                  \
+    else                                                                                         \
+        hipLaunchKernelGGL(yh::loss_fwd_bwd_generic_kernel<PIPE>, grid, dim3(yh::LOSS_THREADS),  \
+                           0, st, pred, gt_xywh, gt_cls, obj_mask, grad_pred, rows_base,         \
+                           (long long)batch, S, Bx, C, g, cellf, imgf, lambda_coord,             \
+                           lambda_noobj, inv_global_batch, pp);
+    if (pipe) { YH_LOSS_LAUNCH(true) } else { YH_LOSS_LAUNCH(false) }
+#undef YH_LOSS_LAUNCH
+    return launch_status();
+}
+
+// the two halves of a pipelined workspace
+struct PipeHalves {
+    char* half[2];
+};
+
+int pipe_halves(void* workspace, size_t workspace_bytes, size_t need_per_half, PipeHalves& h) {
+    if (!workspace) return YH_ERR_WORKSPACE;
+    if (!aligned(workspace, 16)) return YH_ERR_ALIGN;
+    const size_t stride = (workspace_bytes / 2) & ~(size_t)15;
+    if (stride < need_per_half) return YH_ERR_WORKSPACE;
+    h.half[0] = (char*)workspace;
+    h.half[1] = (char*)workspace + stride;
+    return YH_OK;
+}
+
+int check_log(const float* loss_terms, const float* log_ring, int log_capacity,
+              const int32_t* log_cursor) {
+    if (log_ring && (!log_cursor || log_capacity < 1)) return YH_ERR_ARG;
+    if (!aligned(loss_terms, 4) || !aligned(log_ring, 4) || !aligned(log_cursor, 4))
+        return YH_ERR_ALIGN;
+    return YH_OK;
+}
+
+}  // namespace
+
+extern "C" {
 
 int yh_loss_partials(const float* pred, const float* gt_xywh, const float* gt_cls,
                      const uint8_t* obj_mask, float* grad_pred, void* workspace,
@@ -136,31 +206,55 @@ int yh_loss_partials(const float* pred, const float* gt_xywh, const float* gt_cl
                      void* stream) {
     if (const int rc = check_shape(batch, S, Bx, C, img_size)) return rc;
     if (!workspace) return YH_ERR_WORKSPACE;
-    if (batch > 0 && (!pred || !gt_xywh || !gt_cls || !obj_mask || !grad_pred)) return YH_ERR_NULL;
     if (workspace_bytes < yh_workspace_bytes(YH_OP_LOSS, batch, S, Bx, C)) return YH_ERR_WORKSPACE;
-    if (!aligned(workspace, 16) || !aligned(gt_xywh, 16) || !aligned(pred, 4) ||
-        !aligned(grad_pred, 4) || !aligned(gt_cls, 4))
-        return YH_ERR_ALIGN;
-    if (isnan(lambda_coord) || isnan(lambda_noobj) || isnan(inv_global_batch)) return YH_ERR_ARG;
+    if (!aligned(workspace, 16)) return YH_ERR_ALIGN;
+    return loss_launch(pred, gt_xywh, gt_cls, obj_mask, grad_pred, (float*)workspace, batch, S, Bx,
+                       C, img_size, lambda_coord, lambda_noobj, inv_global_batch, nullptr,
+                       (hipStream_t)stream);
+}
 
-    hipStream_t st = (hipStream_t)stream;
-    float* partials = (float*)workspace;
-    const int64_t rows = loss_blocks(batch, S);
-    if (rows == 0) return YH_OK;
-    const int g = loss_imgs_per_block(S);
-    const float cellf = (float)(img_size / S);
-    const float imgf = (float)img_size;
-    if (S == 7 && Bx == 2 && C == 20 && aligned(gt_cls, 16)) {
-        hipLaunchKernelGGL((yh::loss_fwd_bwd_kernel<7, 2, 20>), dim3((unsigned)rows),
-                           dim3(yh::LOSS_THREADS), 0, st, pred, gt_xywh, gt_cls, obj_mask,
-                           grad_pred, partials, (long long)batch, g, cellf, imgf,
-                           lambda_coord, lambda_noobj, inv_global_batch);
-    } else {
-        hipLaunchKernelGGL(yh::loss_fwd_bwd_generic_kernel, dim3((unsigned)rows),
-                           dim3(yh::LOSS_THREADS), 0, st, pred, gt_xywh, gt_cls, obj_mask,
-                           grad_pred, partials, (long long)batch, S, Bx, C, g, cellf, imgf,
-                           lambda_coord, lambda_noobj, inv_global_batch);
+int yh_loss_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+    if (!workspace || workspace_bytes < 64) return YH_ERR_WORKSPACE;
+    if (!aligned(workspace, 16)) return YH_ERR_ALIGN;
+    return (int)hipMemsetAsync(workspace, 0, workspace_bytes, (hipStream_t)stream);
+}
+
+int yh_loss_fwd_bwd_pipelined(const float* pred, const float* gt_xywh, const float* gt_cls,
+                              const uint8_t* obj_mask, float* grad_pred, float* loss_terms_prev,
+                              float* log_ring, int log_capacity, int32_t* log_cursor,
+                              void* workspace, size_t workspace_bytes, int phase, int64_t batch,
+                              int S, int Bx, int C, int img_size, float lambda_coord,
+                              float lambda_noobj, float inv_global_batch, void* stream) {
+    if (const int rc = check_shape(batch, S, Bx, C, img_size)) return rc;
+    if (phase != 0 && phase != 1) return YH_ERR_ARG;
+    if (const int rc = check_log(loss_terms_prev, log_ring, log_capacity, log_cursor)) return rc;
+    PipeHalves h;
+    const size_t need = yh_workspace_bytes(YH_OP_LOSS_PIPELINED, batch, S, Bx, C) / 2;
+    if (const int rc = pipe_halves(workspace, workspace_bytes, need, h)) return rc;
+    char* own = h.half[phase];
+    char* prev = h.half[1 - phase];
+    const yh::LossPipe pipe{(int*)own, (int*)prev, (const float*)(prev + 16), loss_terms_prev,
+                            log_ring, (int*)log_cursor, log_capacity};
+    return loss_launch(pred, gt_xywh, gt_cls, obj_mask, grad_pred, (float*)(own + 16), batch, S,
+                       Bx, C, img_size, lambda_coord, lambda_noobj, inv_global_batch, &pipe,
+                       (hipStream_t)stream);
+}
+
+int yh_loss_pipelined_flush(void* workspace, size_t workspace_bytes, int phase, float* loss_terms,
+                            float* log_ring, int log_capacity, int32_t* log_cursor,
+                            void* stream) {
+    if (phase != 0 && phase != 1) return YH_ERR_ARG;
+    if (const int rc = check_log(loss_terms, log_ring, log_capacity, log_cursor)) return rc;
+    PipeHalves h;
+    if (const int rc = pipe_halves(workspace, workspace_bytes, 32, h)) return rc;
+    yh::LossPipe pipe[2];
+    for (int i = 0; i < 2; ++i) {
+        char* half = h.half[i == 0 ? phase : 1 - phase];
+        pipe[i] = yh::LossPipe{nullptr, (int*)half, (const float*)(half + 16), loss_terms,
+                               log_ring, (int*)log_cursor, log_capacity};
     }
+    hipLaunchKernelGGL(yh::loss_pipe_flush_kernel, dim3(1), dim3(yh::LOSS_THREADS), 0,
+                       (hipStream_t)stream, pipe[0], pipe[1]);
     return launch_status();
 }
 
@@ -176,7 +270,7 @@ int yh_loss_finalize(const void* workspace, size_t workspace_bytes, int64_t batc
         !aligned(log_cursor, 4))
         return YH_ERR_ALIGN;
     if (isnan(inv_global_batch)) return YH_ERR_ARG;
-    hipLaunchKernelGGL(yh::loss_finalize_kernel, dim3(1), dim3(yh::FINALIZE_THREADS), 0,
+    hipLaunchKernelGGL(yh::loss_finalize_kernel, dim3(1), dim3(yh::LOSS_THREADS), 0,
                        (hipStream_t)stream,
                        (const float*)workspace, (int)loss_blocks(batch, S), inv_global_batch,
                        loss_terms, log_ring, log_capacity, (int*)log_cursor);

@@ -117,6 +117,7 @@ class YOLOv1Head(nn.Module):
         self.backbone = backbone
         self.last_loss_terms: Optional[torch.Tensor] = None
         self._workspace = {}
+        self._pipe = {}          # device -> [workspace, phase of the last pipelined call]
         _lib.load()  # fail at construction time if the HIP library is missing
 
     # ------------------------------------------------------------------ helpers
@@ -190,6 +191,61 @@ class YOLOv1Head(nn.Module):
                 0 if log is None else log.capacity,
                 None if log is None else log.cursor.data_ptr(), fst))
         return terms, grad
+
+    def loss_step_pipelined(self, out, gt_norm_xywh, gt_cls_prob, obj_mask, log: "LossLog",
+                            global_batch=None, terms_prev: Optional[torch.Tensor] = None):
+        """One launch per step for loops that only log the loss: writes and returns
+        grad = d(total/global_batch)/d(out); the step's four sums reach ``log`` during
+        the NEXT call (its first workgroup adds them), or at ``flush_loss_log``.
+        ``terms_prev`` (5 floats) receives the previous step's terms.
+
+        The calls alternate between the two halves of a workspace the head keeps
+        per device; capture an even number of them when building a HIP graph."""
+        out = self._check_out(out.detach())
+        bsz, n = out.shape[0], self.n_grid
+        _need(gt_norm_xywh, "gt_norm_xywh", torch.float32, (bsz, n, 1, 4))
+        _need(gt_cls_prob, "gt_cls_prob", torch.float32, (bsz, n, 1, self.n_classes))
+        if obj_mask.dtype == torch.bool:
+            obj_mask = obj_mask.view(torch.uint8)
+        _need(obj_mask, "obj_mask", torch.uint8, (bsz, n, 1, 1))
+        if terms_prev is not None:
+            _need(terms_prev, "terms_prev", torch.float32, (5,))
+        for name, t in (("gt_norm_xywh", gt_norm_xywh), ("gt_cls_prob", gt_cls_prob),
+                        ("obj_mask", obj_mask), ("log", log.ring)):
+            if t.device != out.device:
+                raise ValueError(f"{name}: on {t.device}, out is on {out.device}")
+        lib = _lib.load()
+        gb = bsz if global_batch is None else int(global_batch)
+        shape = (bsz, self.n_cells, self.n_bboxes, self.n_classes)
+        nbytes = lib.yh_workspace_bytes(_lib.YH_OP_LOSS_PIPELINED, *shape)
+        state = self._pipe.get(out.device)
+        if state is None or state[0].numel() < nbytes:
+            if state is not None:
+                self.flush_loss_log(log)         # the halves move: log what is pending first
+            # zero-filled: the headers of the two halves say "nothing pending"
+            state = [torch.zeros(max(nbytes, 1 << 16), dtype=torch.uint8, device=out.device), 1]
+            self._pipe[out.device] = state
+        ws, phase = state[0], 1 - state[1]
+        grad = torch.empty_like(out)
+        with torch.cuda.device(out.device):
+            _lib.check(lib.yh_loss_fwd_bwd_pipelined(
+                out.data_ptr(), gt_norm_xywh.data_ptr(), gt_cls_prob.data_ptr(),
+                obj_mask.data_ptr(), grad.data_ptr(), _ptr(terms_prev), log.ring.data_ptr(),
+                log.capacity, log.cursor.data_ptr(), ws.data_ptr(), ws.numel(), phase, *shape,
+                self.img_size, self.coord_coeff, self.noobj_coeff, 1.0 / max(gb, 1),
+                _stream(out.device)))
+        state[1] = phase
+        return grad
+
+    def flush_loss_log(self, log: "LossLog", terms: Optional[torch.Tensor] = None):
+        """Logs the step ``loss_step_pipelined`` still holds back (no-op if none)."""
+        state = self._pipe.get(log.ring.device)
+        if state is None:
+            return
+        with torch.cuda.device(log.ring.device):
+            _lib.check(_lib.load().yh_loss_pipelined_flush(
+                state[0].data_ptr(), state[0].numel(), state[1], _ptr(terms), log.ring.data_ptr(),
+                log.capacity, log.cursor.data_ptr(), _stream(log.ring.device)))
 
     def loss_fwd_bwd(self, out, gt_norm_xywh, gt_cls_prob, obj_mask, global_batch=None,
                      log: Optional[LossLog] = None,
