@@ -272,6 +272,18 @@ def main():
     loss_flush()
     torch.cuda.synchronize()
     log.reset()
+    # untimed rehearsal of the bookkeeping around the steps (ring copy, collective,
+    # concatenation of the reduced rows): the first use of each loads code on the host
+    rehearsal = LossAllReducer()
+    for _ in range(2):
+        run_steps(spg)
+        loss_flush()
+        with torch.cuda.stream(s_loss):
+            rehearsal.flush(log.ring, spg)
+    with torch.cuda.stream(s_loss):
+        rehearsal.results()
+    torch.cuda.synchronize()
+    log.reset()
 
     # ---- timed region: exactly K steps ------------------------------------------
     say("warm-up done")
@@ -285,9 +297,12 @@ def main():
         with torch.cuda.stream(s_loss):          # ordered after the loss kernels that filled the ring
             reducer.flush(log.ring, n)
         done += n
+        say(f"chunk of {n} enqueued at {1e3 * (time.perf_counter() - t0):.3f} ms")
     with torch.cuda.stream(s_loss):
         losses = reducer.results()                  # waits for the collectives (stream-ordered)
+    say(f"results at {1e3 * (time.perf_counter() - t0):.3f} ms")
     torch.cuda.synchronize()
+    say(f"synchronized at {1e3 * (time.perf_counter() - t0):.3f} ms")
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0

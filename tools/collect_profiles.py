@@ -28,7 +28,7 @@ for counter, d in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir)):
 with open(f"profiles/{tag}_pmc_hbm_traffic.csv", "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["# rocprofv3 --pmc FETCH_SIZE -- python tools/pmc_driver.py  and  rocprofv3 --pmc WRITE_SIZE -- python tools/pmc_driver.py (separate passes); Counter_Value in KiB"])
-    w.writerow(["# the two rocclr_copyBuffer dispatches of 64 MiB are the calibration copies (known bytes): FETCH_SIZE reads 1/2 of the bytes, WRITE_SIZE exact; then 3 launches of the loss kernel and 3 of decode+NMS, batch 4096"])
+    w.writerow(["# the two rocclr_copyBuffer dispatches of 64 MiB are the calibration copies (known bytes): FETCH_SIZE reads 1/2 of the bytes, WRITE_SIZE exact; then 4 launches of the loss kernel (pipelined step) and 3 of decode+NMS, batch 4096"])
     w.writerow(["counter", "dispatch", "kernel", "grid", "workgroup", "vgpr", "value_KiB"])
     w.writerows(out)
 med = lambda x: sorted(x)[len(x) // 2]

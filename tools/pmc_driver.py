@@ -3,7 +3,7 @@
 Launch order: two calibration copies with known byte counts -- a 16-byte-per-lane
 copy and a 4-byte-per-lane copy (source offset by one float so PyTorch's copy
 kernel cannot vectorise) -- then the loss kernel and the decode+NMS kernel of the
-benchmark workload (batch 4096), three launches each."""
+benchmark workload (batch 4096), four and three launches."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,9 +21,12 @@ x = torch.randn(n + 4, device=dev); y = torch.empty(n + 4, device=dev)
 torch.cuda.synchronize()
 y[:n].copy_(x[:n]); torch.cuda.synchronize()          # calibration 1: 16 B per lane
 y[:n].copy_(x[1:n + 1]); torch.cuda.synchronize()     # calibration 2: 4 B per lane
-for _ in range(3):
-    lib.yh_loss_partials(pred.data_ptr(), gx.data_ptr(), gc.data_ptr(), om8.data_ptr(), grad.data_ptr(),
-                         ws.data_ptr(), ws.numel(), B, 7, 2, 20, 448, 5.0, 0.5, 1.0 / B, st)
+wsp = torch.zeros(lib.yh_workspace_bytes(_lib.YH_OP_LOSS_PIPELINED, B, 7, 2, 20), dtype=torch.uint8, device=dev)
+ring = torch.zeros(64, 4, device=dev); cur = torch.zeros(1, dtype=torch.int32, device=dev)
+for i in range(4):                       # the pipelined step the benchmark runs
+    lib.yh_loss_fwd_bwd_pipelined(pred.data_ptr(), gx.data_ptr(), gc.data_ptr(), om8.data_ptr(), grad.data_ptr(),
+                                  None, ring.data_ptr(), 64, cur.data_ptr(), wsp.data_ptr(), wsp.numel(), i & 1,
+                                  B, 7, 2, 20, 448, 5.0, 0.5, 1.0 / B, st)
     torch.cuda.synchronize()
 for _ in range(3):
     lib.yh_decode_nms(pred.data_ptr(), dets.data_ptr(), cnt.data_ptr(), None, MODE_REFERENCE, 0.5, 0.5,
