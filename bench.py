@@ -406,7 +406,7 @@ def main():
         result["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "loss_fwd_bwd_kernel<7,2,20,%s>" % ("true" if pipelined else "false"),
+            "kernel": "loss_fwd_bwd_kernel<7,2,20,%s,false>" % ("true" if pipelined else "false"),
             "algorithmic_bytes_per_launch": algo,
             "kernel_us": t_loss["back_to_back_us"],
         }

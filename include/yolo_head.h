@@ -145,6 +145,32 @@ int yh_loss_pipelined_flush(void* workspace, size_t workspace_bytes, int phase, 
                             float* log_ring, int log_capacity, int32_t* log_cursor, void* stream);
 
 /*
+ * The last layer's bias and view folded into the head read (model.py:133-135,
+ * 146-148: nn.Linear(4096, S*S*D) followed by .view(-1, D, S, S)).  `z`
+ * (batch, S*S*D) is that layer's matrix product WITHOUT the bias, read in place as
+ * (batch, D, S, S) -- the view is free, no cell-major staging copy exists in this
+ * library -- and `bias` (S*S*D floats, the layer's bias) is added as each logit is
+ * read: the result equals the unfused call on z + bias bit for bit.
+ * yh_loss_fwd_bwd_linear: as yh_loss_fwd_bwd; grad_z is the gradient with respect
+ * to z (equal to the one with respect to z + bias).
+ * yh_decode_nms_linear: as yh_decode_nms.
+ * yh_bias_grad: grad_bias[c] = sum over rows of grad (nrows, ncols) in a fixed
+ * order (bitwise reproducible) -- the bias gradient of the layer's backward, with
+ * nrows = batch, ncols = S*S*D.  workspace: yh_bias_grad_workspace_bytes bytes.
+ */
+int yh_loss_fwd_bwd_linear(const float* z, const float* bias, const float* gt_xywh,
+                           const float* gt_cls, const uint8_t* obj_mask, float* grad_z,
+                           float* loss_terms, void* workspace, size_t workspace_bytes,
+                           int64_t batch, int S, int Bx, int C, int img_size, float lambda_coord,
+                           float lambda_noobj, float inv_global_batch, void* stream);
+int yh_decode_nms_linear(const float* z, const float* bias, float* dets, int32_t* keep_count,
+                         int32_t* keep_idx, int mode, float conf_thresh, float iou_thresh,
+                         int64_t batch, int S, int Bx, int C, int img_size, void* stream);
+size_t yh_bias_grad_workspace_bytes(int64_t nrows, int ncols);
+int yh_bias_grad(const float* grad, float* grad_bias, void* workspace, size_t workspace_bytes,
+                 int64_t nrows, int ncols, void* stream);
+
+/*
  * grad[i] *= *scale for i < n, in place; does not touch memory when *scale == 1.
  * `scale` is a device scalar: the grad_output that reaches the head's backward
  * (1 for loss.backward(), the GradScaler scale for

@@ -61,6 +61,14 @@ SIGNATURES = {
                                           c_float, c_float, c_void_p]),
     "yh_loss_pipelined_flush": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_int,
                                         c_void_p, c_void_p]),
+    "yh_loss_fwd_bwd_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int,
+                                       c_int, c_float, c_float, c_float, c_void_p]),
+    "yh_decode_nms_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_float, c_float, c_int64, c_int, c_int, c_int, c_int,
+                                     c_void_p]),
+    "yh_bias_grad_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "yh_bias_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_void_p]),
     "yh_scale_grad": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "yh_pairwise_boxes": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "yh_box_area": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void decode_grid_kernel(
         const long long img = g / S2;
         const int cell = (int)(g - img * S2);
         const float* p = pred + img * D * S2 + cell;
-        const MemLogits logit{p, S2};
+        const MemLogits logit{p, nullptr, S2};
         if (ltrb || conf) {
             for (int k = 0; k < nb; ++k) {
                 if (ltrb) {
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void decode_grid_kernel(
             }
             if (conf_mask) conf_mask[g] = cb >= conf_thresh ? 1 : 0;
         }
-        if (cls_idx) cls_idx[g] = cell_class_mem(p, 5 * nb, nc, S2);
+        if (cls_idx) cls_idx[g] = cell_class_mem(logit, 5 * nb, nc);
         if (cls_prob) {
             const float* pc = p + 5 * nb * S2;
             float m = pc[0];

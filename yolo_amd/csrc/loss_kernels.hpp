@@ -183,10 +183,15 @@ __device__ __forceinline__ void loss_obj_cell(const L& logit, float* __restrict_
 }
 
 // reads a cell's channels from the head tensor on use
+template <bool BIAS>
 struct GlobalLogits {
     const float* __restrict__ p;
+    const float* __restrict__ b;   // the cell's bias values, channels S2 apart (BIAS only)
     int S2;
-    __device__ __forceinline__ float operator()(int ch) const { return p[ch * S2]; }
+    __device__ __forceinline__ float operator()(int ch) const {
+        if constexpr (BIAS) return p[ch * S2] + b[ch * S2];
+        else return p[ch * S2];
+    }
 };
 
 // wave -> workgroup reduction of the three partial sums in a fixed order; one
@@ -309,9 +314,12 @@ __device__ __forceinline__ void loss_pipe_log(const LossPipe& p, int own_rows, f
 }
 
 // Run-time shape (any S, Bx, C within the limits): channels are read on use.
-template <bool PIPE>
+// BIAS: `pred` is the last layer's output before its bias (model.py:133-135) and
+// `bias` (one image's worth of values, same layout) is added as the logits are read.
+template <bool PIPE, bool BIAS>
 __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
-    const float* __restrict__ pred, const float* __restrict__ gt_xywh,
+    const float* __restrict__ pred, const float* __restrict__ bias,
+    const float* __restrict__ gt_xywh,
     const float* __restrict__ gt_cls, const uint8_t* __restrict__ obj_mask,
     float* __restrict__ grad, float* __restrict__ partials, long long batch, int S, int nb,
     int nc, int imgs_per_block, float cellf, float imgf, float lc, float ln, float inv_gb,
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
         if (img < batch) {
             const long long tcell = img * S2 + cell;
             const long long off = img * D * S2 + cell;
-            const GlobalLogits logit{pred + off, S2};
+            const GlobalLogits<BIAS> logit{pred + off, BIAS ? bias + cell : nullptr, S2};
             if (obj_mask[tcell] != 0)
                 loss_obj_cell<0>(logit, grad + off, gt_xywh + tcell * 4, gt_cls + tcell * nc, cell,
                                  S, S2, nb, nc, cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf,
@@ -356,9 +364,10 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
 // (Compacting the object cells of a workgroup into one wavefront through LDS was
 // measured slower here: the barriers and the single-wave object path lengthen
 // each workgroup's critical path more than the saved VALU work is worth.)
-template <int S, int BX, int C, bool PIPE>
+template <int S, int BX, int C, bool PIPE, bool BIAS>
 __global__ __launch_bounds__(LOSS_THREADS, 4) void loss_fwd_bwd_kernel(
-    const float* __restrict__ pred, const float* __restrict__ gt_xywh,
+    const float* __restrict__ pred, const float* __restrict__ bias,
+    const float* __restrict__ gt_xywh,
     const float* __restrict__ gt_cls, const uint8_t* __restrict__ obj_mask,
     float* __restrict__ grad, float* __restrict__ partials, long long batch,
     int imgs_per_block, float cellf, float imgf, float lc, float ln, float inv_gb,
@@ -388,6 +397,11 @@ __global__ __launch_bounds__(LOSS_THREADS, 4) void loss_fwd_bwd_kernel(
             float v[D];
 #pragma unroll
             for (int ch = 0; ch < D; ++ch) v[ch] = p[ch * S2];
+            if constexpr (BIAS) {
+                const float* bq = bias + cell;
+#pragma unroll
+                for (int ch = 0; ch < D; ++ch) v[ch] += bq[ch * S2];
+            }
             auto logit = [&](int ch) -> float { return v[ch]; };
             if (obj_mask[tcell] != 0)
                 loss_obj_cell<C>(logit, grad + off, gt_xywh + tcell * 4, gt_cls + tcell * C, cell,
@@ -419,6 +433,44 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_pipe_flush_kernel(LossPipe 
     loss_pipe_log(last, 0, 0.f);
     __syncthreads();
     loss_pipe_log(other, 0, 0.f);
+}
+
+// Column sums of a (nrows, ncols) matrix in a fixed order.  Block (x, y) covers
+// columns [64 x, 64 x + 64) of rows [y * rows_per_slice, (y + 1) * rows_per_slice):
+// wavefront w adds rows w, w + 4, ... of the slice (eight loads in flight), the
+// four sums are added in wavefront order, the result goes to row y of `out`.  A
+// second launch over those rows finishes.  Used for the gradient of the last
+// layer's bias: the sum of grad_pred over the batch.
+__global__ __launch_bounds__(256) void column_sum_kernel(const float* __restrict__ in,
+                                                         float* __restrict__ out, long long nrows,
+                                                         int ncols, int rows_per_slice) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const long long r0 = (long long)blockIdx.y * rows_per_slice;
+    const long long r1 = r0 + rows_per_slice < nrows ? r0 + rows_per_slice : nrows;
+    float acc = 0.f;
+    if (col < ncols) {
+        long long r = r0 + w;
+        const float* p = in + r * ncols + col;
+        for (; r + 28 < r1; r += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(long long)(4 * u) * ncols];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+            p += 32LL * ncols;
+        }
+        for (; r < r1; r += 4) {
+            acc += *p;
+            p += 4LL * ncols;
+        }
+    }
+    part[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && col < ncols)
+        out[(long long)blockIdx.y * ncols + col] =
+            ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
 // grad[i] *= *scale, skipped entirely when *scale == 1 (the loss.backward() case).

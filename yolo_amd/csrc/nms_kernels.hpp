@@ -25,8 +25,10 @@ namespace yh {
 constexpr int NMS_BLOCK = 256;
 
 struct NmsArgs {
-    // source 0: the head tensor
+    // source 0: the head tensor; source 2: the head tensor before the last layer's
+    // bias was added, plus that bias (one image's worth of values, same layout)
     const float* pred;
+    const float* bias;
     // source 1: caller-supplied candidates
     const float* c_ltrb;
     const float* c_score;
@@ -54,11 +56,17 @@ struct NmsArgs {
 // that decodes a cell produces the same bits.
 
 // reads the cell's channels from the head tensor on use
-struct MemLogits {
+template <bool BIAS>
+struct MemLogitsT {
     const float* __restrict__ p;
+    const float* __restrict__ b;   // the cell's bias values, channels S2 apart (BIAS only)
     int S2;
-    __device__ __forceinline__ float operator()(int ch) const { return p[ch * S2]; }
+    __device__ __forceinline__ float operator()(int ch) const {
+        if constexpr (BIAS) return p[ch * S2] + b[ch * S2];
+        else return p[ch * S2];
+    }
 };
+using MemLogits = MemLogitsT<false>;
 
 // class of a cell: argmax of the class logits, first index on ties
 template <class L>
@@ -75,13 +83,14 @@ __device__ __forceinline__ int cell_class(const L& logit, int c0, int nc) {
 
 // run-time class count: the logits are fetched eight at a time so that one cell
 // costs nc/8 memory round trips instead of nc
-__device__ __forceinline__ int cell_class_mem(const float* __restrict__ p, int c0, int nc, int S2) {
+template <class L>
+__device__ __forceinline__ int cell_class_mem(const L& logit, int c0, int nc) {
     int best = 0;
-    float m = p[c0 * S2];
+    float m = logit(c0);
     for (int j0 = 1; j0 < nc; j0 += 8) {
         float t[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = (j0 + u < nc) ? p[(c0 + j0 + u) * S2] : 0.0f;
+        for (int u = 0; u < 8; ++u) t[u] = (j0 + u < nc) ? logit(c0 + j0 + u) : 0.0f;
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (j0 + u < nc && t[u] > m) { m = t[u]; best = j0 + u; }
@@ -135,8 +144,10 @@ template <int NT, int ITEMS, int SRC, int S_CT, int BX_CT, int C_CT>
 __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int IPB = NMS_BLOCK / NT;  // images per workgroup
+    constexpr bool kHead = SRC == 0 || SRC == 2;   // candidates decoded from the head tensor
+    constexpr bool kBias = SRC == 2;               // ... to which a bias is added on the way in
     // class-bucketed ranking: a workgroup per image, class count known and bounded
-    constexpr bool kBucket = NT != 64 && SRC == 0;
+    constexpr bool kBucket = NT != 64 && kHead;
     constexpr int NW = NT / 64;          // wavefronts per image
     const int sub = threadIdx.x / NT;
     const int t = threadIdx.x % NT;
@@ -171,7 +182,7 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
     }
     if (t == 0) { misc[0] = 0; misc[1] = 0; }
 
-    if constexpr (SRC == 0) {
+    if constexpr (kHead) {
         constexpr bool kStatic = BX_CT > 0 && C_CT > 0;
         // all channels of a cell in registers only while that stays cheap
         constexpr bool kStaticCell = kStatic && (5 * BX_CT + C_CT <= 48);
@@ -193,6 +204,11 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
                         float v[5 * BX_CT + C_CT];
 #pragma unroll
                         for (int ch = 0; ch < 5 * BX_CT + C_CT; ++ch) v[ch] = p[ch * S2];
+                        if constexpr (kBias) {
+                            const float* bq = a.bias + cell;
+#pragma unroll
+                            for (int ch = 0; ch < 5 * BX_CT + C_CT; ++ch) v[ch] += bq[ch * S2];
+                        }
                         auto logit = [&](int ch) -> float { return v[ch]; };
                         k = cell_best_conf(logit, BX_CT, cb);
                         float lx = v[0], ly = v[1], lw = v[2], lh = v[3];
@@ -202,10 +218,10 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
                         cbox[e] = box_from_logits(lx, ly, lw, lh, cell, S, a.cellf, a.imgf);
                         ccl[e] = cell_class(logit, 5 * BX_CT, C_CT);
                     } else {
-                        const MemLogits logit{p, S2};
+                        const MemLogitsT<kBias> logit{p, kBias ? a.bias + cell : nullptr, S2};
                         k = cell_best_conf(logit, nb, cb);
                         cbox[e] = cell_box(logit, k, cell, S, a.cellf, a.imgf);
-                        ccl[e] = cell_class_mem(p, 5 * nb, nc, S2);
+                        ccl[e] = cell_class_mem(logit, 5 * nb, nc);
                     }
                     cscore[e] = cb;
                     cidx[e] = cell * nb + k;
@@ -223,10 +239,16 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
                     float v[C_CT];
 #pragma unroll
                     for (int j = 0; j < C_CT; ++j) v[j] = p[(5 * BX_CT + j) * S2];
+                    if constexpr (kBias) {
+                        const float* bq = a.bias + cell;
+#pragma unroll
+                        for (int j = 0; j < C_CT; ++j) v[j] += bq[(5 * BX_CT + j) * S2];
+                    }
                     auto logit = [&](int ch) -> float { return v[ch]; };
                     ccls[cell] = cell_class(logit, 0, C_CT);
                 } else {
-                    ccls[cell] = cell_class_mem(p, 5 * nb, nc, S2);
+                    ccls[cell] = cell_class_mem(
+                        MemLogitsT<kBias>{p, kBias ? a.bias + cell : nullptr, S2}, 5 * nb, nc);
                 }
             }
             group_sync<NT>();
@@ -236,8 +258,9 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
                 if (n < nslot) {
                     const int cell = n / nb;
                     const int k = n - cell * nb;
-                    const float* p = pimg + cell + (5 * k) * S2;
-                    const float lx = p[0], ly = p[S2], lw = p[2 * S2], lh = p[3 * S2], lc = p[4 * S2];
+                    const MemLogitsT<kBias> q{pimg + cell + (5 * k) * S2,
+                                              kBias ? a.bias + cell + (5 * k) * S2 : nullptr, S2};
+                    const float lx = q(0), ly = q(1), lw = q(2), lh = q(3), lc = q(4);
                     cbox[e] = box_from_logits(lx, ly, lw, lh, cell, S, a.cellf, a.imgf);
                     cscore[e] = sigmoidf_(lc);
                     ccl[e] = ccls[cell];
@@ -502,8 +525,8 @@ __global__ __launch_bounds__(256) void decode_candidates_kernel(
         const long long img = g / S2;
         const int cell = (int)(g - img * S2);
         const float* p = pred + img * D * S2 + cell;
-        const MemLogits logit{p, S2};
-        const int cls = cell_class_mem(p, 5 * nb, nc, S2);
+        const MemLogits logit{p, nullptr, S2};
+        const int cls = cell_class_mem(logit, 5 * nb, nc);
         float cb;
         const int best = cell_best_conf(logit, nb, cb);
         for (int k = 0; k < nb; ++k) {

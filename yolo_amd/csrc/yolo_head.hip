@@ -66,6 +66,14 @@ void nms_layout(yh::NmsArgs& a, int slot_pad) {
     a.region_bytes = off;
 }
 
+// row slices of the first column-sum pass: about 32 rows each, at most 1024 slices
+int colsum_slices(int64_t nrows) {
+    int64_t s = (nrows + 31) / 32;
+    if (s < 1) s = 1;
+    if (s > 1024) s = 1024;
+    return (int)s;
+}
+
 template <int SRC, int S_CT, int BX_CT, int C_CT>
 int launch_nms_shape(yh::NmsArgs a, hipStream_t st) {
 #define YH_NMS_CASE(NT, ITEMS)                                                              \
@@ -94,6 +102,9 @@ int launch_nms(const yh::NmsArgs& a, hipStream_t st) {
         // the two shapes the head is benchmarked on get compile-time channel counts
         if (a.S == 7 && a.nb == 2 && a.nc == 20) return launch_nms_shape<0, 7, 2, 20>(a, st);
         if (a.S == 14 && a.nb == 5 && a.nc == 80) return launch_nms_shape<0, 14, 5, 80>(a, st);
+    }
+    if constexpr (SRC == 2) {
+        if (a.S == 7 && a.nb == 2 && a.nc == 20) return launch_nms_shape<2, 7, 2, 20>(a, st);
     }
     return launch_nms_shape<SRC, 0, 0, 0>(a, st);
 }
@@ -138,7 +149,7 @@ namespace {
 
 // Argument checks and launch shared by yh_loss_partials (pipe == nullptr, rows at
 // `rows_base`) and the pipelined step (workgroup 0 logs the previous call).
-int loss_launch(const float* pred, const float* gt_xywh, const float* gt_cls,
+int loss_launch(const float* pred, const float* bias, const float* gt_xywh, const float* gt_cls,
                 const uint8_t* obj_mask, float* grad_pred, float* rows_base, int64_t batch,
                 int S, int Bx, int C, int img_size, float lambda_coord, float lambda_noobj,
                 float inv_global_batch, const yh::LossPipe* pipe, hipStream_t st) {
@@ -153,20 +164,31 @@ int loss_launch(const float* pred, const float* gt_xywh, const float* gt_cls,
     const int g = loss_imgs_per_block(S);
     const float cellf = (float)(img_size / S);
     const float imgf = (float)img_size;
+    if (!aligned(bias, 4)) return YH_ERR_ALIGN;
     const bool fast = S == 7 && Bx == 2 && C == 20 && aligned(gt_cls, 16);
     const yh::LossPipe pp = pipe ? *pipe : yh::LossPipe{};
     const dim3 grid((unsigned)(rows + (pipe ? 1 : 0)));
 #define YH_LOSS_LAUNCH(PIPE)                                                                     \
-    if (fast)                                                                                    \
-        hipLaunchKernelGGL((yh::loss_fwd_bwd_kernel<7, 2, 20, PIPE>), grid,                      \
-                           dim3(yh::LOSS_THREADS), 0, st, pred, gt_xywh, gt_cls, obj_mask,       \
+    if (fast && bias)                                                                            \
+        hipLaunchKernelGGL((yh::loss_fwd_bwd_kernel<7, 2, 20, PIPE, true>), grid,                \
+                           dim3(yh::LOSS_THREADS), 0, st, pred, bias, gt_xywh, gt_cls, obj_mask, \
                            grad_pred, rows_base, (long long)batch, g, cellf, imgf, lambda_coord, \
                            lambda_noobj, inv_global_batch, pp);                                  \
+    else if (fast)                                                                               \
+        hipLaunchKernelGGL((yh::loss_fwd_bwd_kernel<7, 2, 20, PIPE, false>), grid,               \
+                           dim3(yh::LOSS_THREADS), 0, st, pred, bias, gt_xywh, gt_cls, obj_mask, \
+                           grad_pred, rows_base, (long long)batch, g, cellf, imgf, lambda_coord, \
+                           lambda_noobj, inv_global_batch, pp);                                  \
+    else if (bias)                                                                               \
+        hipLaunchKernelGGL((yh::loss_fwd_bwd_generic_kernel<PIPE, true>), grid,                  \
+                           dim3(yh::LOSS_THREADS), 0, st, pred, bias, gt_xywh, gt_cls, obj_mask, \
+                           grad_pred, rows_base, (long long)batch, S, Bx, C, g, cellf, imgf,     \
+                           lambda_coord, lambda_noobj, inv_global_batch, pp);                    \
     else                                                                                         \
-        hipLaunchKernelGGL(yh::loss_fwd_bwd_generic_kernel<PIPE>, grid, dim3(yh::LOSS_THREADS),  \
-                           0, st, pred, gt_xywh, gt_cls, obj_mask, grad_pred, rows_base,         \
-                           (long long)batch, S, Bx, C, g, cellf, imgf, lambda_coord,             \
-                           lambda_noobj, inv_global_batch, pp);
+        hipLaunchKernelGGL((yh::loss_fwd_bwd_generic_kernel<PIPE, false>), grid,                 \
+                           dim3(yh::LOSS_THREADS), 0, st, pred, bias, gt_xywh, gt_cls, obj_mask, \
+                           grad_pred, rows_base, (long long)batch, S, Bx, C, g, cellf, imgf,     \
+                           lambda_coord, lambda_noobj, inv_global_batch, pp);
     if (pipe) { YH_LOSS_LAUNCH(true) } else { YH_LOSS_LAUNCH(false) }
 #undef YH_LOSS_LAUNCH
     return launch_status();
@@ -208,9 +230,9 @@ int yh_loss_partials(const float* pred, const float* gt_xywh, const float* gt_cl
     if (!workspace) return YH_ERR_WORKSPACE;
     if (workspace_bytes < yh_workspace_bytes(YH_OP_LOSS, batch, S, Bx, C)) return YH_ERR_WORKSPACE;
     if (!aligned(workspace, 16)) return YH_ERR_ALIGN;
-    return loss_launch(pred, gt_xywh, gt_cls, obj_mask, grad_pred, (float*)workspace, batch, S, Bx,
-                       C, img_size, lambda_coord, lambda_noobj, inv_global_batch, nullptr,
-                       (hipStream_t)stream);
+    return loss_launch(pred, nullptr, gt_xywh, gt_cls, obj_mask, grad_pred, (float*)workspace,
+                       batch, S, Bx, C, img_size, lambda_coord, lambda_noobj, inv_global_batch,
+                       nullptr, (hipStream_t)stream);
 }
 
 int yh_loss_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
@@ -235,9 +257,9 @@ int yh_loss_fwd_bwd_pipelined(const float* pred, const float* gt_xywh, const flo
     char* prev = h.half[1 - phase];
     const yh::LossPipe pipe{(int*)own, (int*)prev, (const float*)(prev + 16), loss_terms_prev,
                             log_ring, (int*)log_cursor, log_capacity};
-    return loss_launch(pred, gt_xywh, gt_cls, obj_mask, grad_pred, (float*)(own + 16), batch, S,
-                       Bx, C, img_size, lambda_coord, lambda_noobj, inv_global_batch, &pipe,
-                       (hipStream_t)stream);
+    return loss_launch(pred, nullptr, gt_xywh, gt_cls, obj_mask, grad_pred, (float*)(own + 16),
+                       batch, S, Bx, C, img_size, lambda_coord, lambda_noobj, inv_global_batch,
+                       &pipe, (hipStream_t)stream);
 }
 
 int yh_loss_pipelined_flush(void* workspace, size_t workspace_bytes, int phase, float* loss_terms,
@@ -289,6 +311,52 @@ int yh_loss_fwd_bwd(const float* pred, const float* gt_xywh, const float* gt_cls
     if (const int rc = yh_loss_partials(pred, gt_xywh, gt_cls, obj_mask, grad_pred, workspace,
                                         workspace_bytes, batch, S, Bx, C, img_size, lambda_coord,
                                         lambda_noobj, inv_global_batch, stream))
+        return rc;
+    return yh_loss_finalize(workspace, workspace_bytes, batch, S, inv_global_batch, loss_terms,
+                            nullptr, 0, nullptr, stream);
+}
+
+size_t yh_bias_grad_workspace_bytes(int64_t nrows, int ncols) {
+    if (nrows < 0 || ncols < 1) return 0;
+    return (size_t)colsum_slices(nrows) * (size_t)ncols * sizeof(float);
+}
+
+int yh_bias_grad(const float* grad, float* grad_bias, void* workspace, size_t workspace_bytes,
+                 int64_t nrows, int ncols, void* stream) {
+    if (nrows < 0 || ncols < 1) return YH_ERR_SHAPE;
+    if (!grad_bias || (nrows > 0 && !grad)) return YH_ERR_NULL;
+    if (!workspace || workspace_bytes < yh_bias_grad_workspace_bytes(nrows, ncols))
+        return YH_ERR_WORKSPACE;
+    if (!aligned(grad, 4) || !aligned(grad_bias, 4) || !aligned(workspace, 4)) return YH_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const int slices = colsum_slices(nrows);
+    const int per = nrows == 0 ? 1 : (int)((nrows + slices - 1) / slices);
+    const unsigned gx = (unsigned)((ncols + 63) / 64);
+    // pass 1: `slices` partial rows; pass 2: their sum (also writes zeros when nrows == 0)
+    if (nrows > 0) {
+        hipLaunchKernelGGL(yh::column_sum_kernel, dim3(gx, (unsigned)slices), dim3(256), 0, st, grad,
+                           (float*)workspace, (long long)nrows, ncols, per);
+        if (const int rc = launch_status()) return rc;
+    }
+    hipLaunchKernelGGL(yh::column_sum_kernel, dim3(gx, 1), dim3(256), 0, st,
+                       (const float*)workspace, grad_bias, (long long)(nrows > 0 ? slices : 0),
+                       ncols, slices);
+    return launch_status();
+}
+
+int yh_loss_fwd_bwd_linear(const float* z, const float* bias, const float* gt_xywh,
+                           const float* gt_cls, const uint8_t* obj_mask, float* grad_z,
+                           float* loss_terms, void* workspace, size_t workspace_bytes,
+                           int64_t batch, int S, int Bx, int C, int img_size, float lambda_coord,
+                           float lambda_noobj, float inv_global_batch, void* stream) {
+    if (const int rc = check_shape(batch, S, Bx, C, img_size)) return rc;
+    if (!loss_terms || !bias) return YH_ERR_NULL;
+    if (!workspace) return YH_ERR_WORKSPACE;
+    if (workspace_bytes < yh_workspace_bytes(YH_OP_LOSS, batch, S, Bx, C)) return YH_ERR_WORKSPACE;
+    if (!aligned(workspace, 16)) return YH_ERR_ALIGN;
+    if (const int rc = loss_launch(z, bias, gt_xywh, gt_cls, obj_mask, grad_z, (float*)workspace,
+                                   batch, S, Bx, C, img_size, lambda_coord, lambda_noobj,
+                                   inv_global_batch, nullptr, (hipStream_t)stream))
         return rc;
     return yh_loss_finalize(workspace, workspace_bytes, batch, S, inv_global_batch, loss_terms,
                             nullptr, 0, nullptr, stream);
@@ -431,19 +499,27 @@ int yh_decode_candidates(const float* pred, float* cand_ltrb, float* cand_score,
     return launch_status();
 }
 
-int yh_decode_nms(const float* pred, float* dets, int32_t* keep_count, int32_t* keep_idx,
-                  int mode, float conf_thresh, float iou_thresh, int64_t batch, int S, int Bx,
-                  int C, int img_size, void* stream) {
+}  // extern "C"
+
+namespace {
+
+int decode_nms_launch(const float* pred, const float* bias, float* dets, int32_t* keep_count,
+                      int32_t* keep_idx, int mode, float conf_thresh, float iou_thresh,
+                      int64_t batch, int S, int Bx, int C, int img_size, bool with_bias,
+                      void* stream) {
     if (const int rc = check_shape(batch, S, Bx, C, img_size)) return rc;
     if (mode != YH_MODE_REFERENCE && mode != YH_MODE_DENSE) return YH_ERR_ARG;
     if (isnan(conf_thresh) || isnan(iou_thresh)) return YH_ERR_ARG;
     if ((int64_t)S * S * Bx > YH_MAX_CANDIDATES) return YH_ERR_UNSUPPORTED;
+    if (with_bias && !bias) return YH_ERR_NULL;
     if (batch == 0) return YH_OK;
     if (!pred || !dets || !keep_count) return YH_ERR_NULL;
-    if (!aligned(pred, 4) || !aligned(dets, 8) || !aligned(keep_count, 4) || !aligned(keep_idx, 4))
+    if (!aligned(pred, 4) || !aligned(bias, 4) || !aligned(dets, 8) || !aligned(keep_count, 4) ||
+        !aligned(keep_idx, 4))
         return YH_ERR_ALIGN;
     yh::NmsArgs a = {};
     a.pred = pred;
+    a.bias = bias;
     a.dets = dets;
     a.keep_count = keep_count;
     a.keep_idx = keep_idx;
@@ -458,7 +534,25 @@ int yh_decode_nms(const float* pred, float* dets, int32_t* keep_count, int32_t* 
 #ifdef YH_PHASE_PROBE
     { const char* e = getenv("YH_NMS_STOP"); a.dbg_stop = e ? atoi(e) : 0; }
 #endif
-    return launch_nms<0>(a, (hipStream_t)stream);
+    return with_bias ? launch_nms<2>(a, (hipStream_t)stream) : launch_nms<0>(a, (hipStream_t)stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int yh_decode_nms(const float* pred, float* dets, int32_t* keep_count, int32_t* keep_idx,
+                  int mode, float conf_thresh, float iou_thresh, int64_t batch, int S, int Bx,
+                  int C, int img_size, void* stream) {
+    return decode_nms_launch(pred, nullptr, dets, keep_count, keep_idx, mode, conf_thresh,
+                             iou_thresh, batch, S, Bx, C, img_size, false, stream);
+}
+
+int yh_decode_nms_linear(const float* z, const float* bias, float* dets, int32_t* keep_count,
+                         int32_t* keep_idx, int mode, float conf_thresh, float iou_thresh,
+                         int64_t batch, int S, int Bx, int C, int img_size, void* stream) {
+    return decode_nms_launch(z, bias, dets, keep_count, keep_idx, mode, conf_thresh, iou_thresh,
+                             batch, S, Bx, C, img_size, true, stream);
 }
 
 int yh_nms(const float* cand_ltrb, const float* cand_score, const int32_t* cand_cls,

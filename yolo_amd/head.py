@@ -95,6 +95,41 @@ class _LossFunction(torch.autograd.Function):
         return grad, None, None, None, None, None
 
 
+class _LinearLossFunction(torch.autograd.Function):
+    """The loss on (z, bias) of the last nn.Linear: the forward launch produces the
+    gradient for z, the bias gradient is its fixed-order sum over the batch."""
+
+    @staticmethod
+    def forward(ctx, z, bias, gt_norm_xywh, gt_cls_prob, obj_mask, head, global_batch):
+        terms, grad, grad_bias = head.loss_fwd_bwd_linear(
+            z, bias, gt_norm_xywh, gt_cls_prob, obj_mask, global_batch,
+            want_bias_grad=bias.requires_grad)
+        ctx.grads = (grad, grad_bias)
+        ctx.bias_shape = bias.shape
+        head.last_loss_terms = terms
+        return terms[4]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        grad, grad_bias = ctx.grads
+        ctx.grads = None
+        if grad is None:
+            raise RuntimeError("YOLOv1Head loss: backward called twice")
+        go = grad_output
+        if go.dtype != torch.float32 or go.numel() != 1 or go.device != grad.device:
+            go = go.to(device=grad.device, dtype=torch.float32).reshape(())
+        lib = _lib.load()
+        with torch.cuda.device(grad.device):
+            _lib.check(lib.yh_scale_grad(grad.data_ptr(), go.data_ptr(), grad.numel(),
+                                         _stream(grad.device)))
+            if grad_bias is not None:
+                _lib.check(lib.yh_scale_grad(grad_bias.data_ptr(), go.data_ptr(), grad_bias.numel(),
+                                             _stream(grad.device)))
+                grad_bias = grad_bias.view(ctx.bias_shape)
+        return grad, grad_bias, None, None, None, None, None
+
+
 class YOLOv1Head(nn.Module):
     def __init__(
         self,
@@ -142,6 +177,14 @@ class YOLOv1Head(nn.Module):
             raise ValueError(f"out: expected shape (B, {self.depth}, {self.n_cells}, "
                              f"{self.n_cells}), got {tuple(out.shape)}")
         return _need(out, "out", torch.float32)
+
+    def _check_bias(self, bias: torch.Tensor, device) -> torch.Tensor:
+        bias = _need(bias.detach(), "bias", torch.float32)
+        if bias.numel() != self.depth * self.n_grid:
+            raise ValueError(f"bias: expected {self.depth * self.n_grid} values, got {bias.numel()}")
+        if bias.device != device:
+            raise ValueError(f"bias: on {bias.device}, the head tensor is on {device}")
+        return bias
 
     def _get_workspace(self, device, nbytes: int) -> torch.Tensor:
         ws = self._workspace.get(device)
@@ -264,6 +307,56 @@ class YOLOv1Head(nn.Module):
         return self._launch_loss(out.detach(), gt_norm_xywh, gt_cls_prob, obj_mask,
                                  1.0 / max(gb, 1), log, finalize_stream)
 
+    def loss_fwd_bwd_linear(self, z, bias, gt_norm_xywh, gt_cls_prob, obj_mask, global_batch=None,
+                            want_bias_grad=True):
+        """The last layer's bias and view folded into the kernel's read: ``z`` (B, S*S*D)
+        is nn.Linear's product without its bias (model.py:133-135), ``bias`` that
+        bias.  Returns (terms, grad_z, grad_bias); grad_z has z's shape, grad_bias is
+        the fixed-order sum of grad_z over the batch (None unless wanted)."""
+        if z.dim() != 2 or z.shape[1] != self.depth * self.n_grid:
+            raise ValueError(f"z: expected shape (B, {self.depth * self.n_grid}), got {tuple(z.shape)}")
+        out = self._check_out(z.detach().view(-1, self.depth, self.n_cells, self.n_cells))
+        bias = self._check_bias(bias, out.device)
+        bsz, n = out.shape[0], self.n_grid
+        _need(gt_norm_xywh, "gt_norm_xywh", torch.float32, (bsz, n, 1, 4))
+        _need(gt_cls_prob, "gt_cls_prob", torch.float32, (bsz, n, 1, self.n_classes))
+        if obj_mask.dtype == torch.bool:
+            obj_mask = obj_mask.view(torch.uint8)
+        _need(obj_mask, "obj_mask", torch.uint8, (bsz, n, 1, 1))
+        lib = _lib.load()
+        gb = bsz if global_batch is None else int(global_batch)
+        shape = (bsz, self.n_cells, self.n_bboxes, self.n_classes)
+        ncols = self.depth * n
+        nbytes = max(lib.yh_workspace_bytes(_lib.YH_OP_LOSS, *shape),
+                     lib.yh_bias_grad_workspace_bytes(bsz, ncols))
+        ws = self._get_workspace(out.device, nbytes)
+        grad = torch.empty_like(z)
+        terms = torch.empty(5, dtype=torch.float32, device=out.device)
+        grad_bias = None
+        with torch.cuda.device(out.device):
+            st = _stream(out.device)
+            _lib.check(lib.yh_loss_fwd_bwd_linear(
+                out.data_ptr(), bias.data_ptr(), gt_norm_xywh.data_ptr(), gt_cls_prob.data_ptr(),
+                obj_mask.data_ptr(), grad.data_ptr(), terms.data_ptr(), ws.data_ptr(), ws.numel(),
+                *shape, self.img_size, self.coord_coeff, self.noobj_coeff, 1.0 / max(gb, 1), st))
+            if want_bias_grad:
+                grad_bias = torch.empty(ncols, dtype=torch.float32, device=out.device)
+                _lib.check(lib.yh_bias_grad(grad.data_ptr(), grad_bias.data_ptr(), ws.data_ptr(),
+                                            ws.numel(), bsz, ncols, st))
+        return terms, grad, grad_bias
+
+    def get_loss_linear(self, z, bias, gt_norm_xywh, gt_cls_prob, obj_mask, global_batch=None):
+        """``get_loss`` for a model whose last nn.Linear hands over its product and its
+        bias separately (model.py:133-135, 146-148): a 0-d loss whose ``.backward()``
+        reaches both ``z`` and ``bias``."""
+        if torch.is_grad_enabled() and (z.requires_grad or bias.requires_grad):
+            return _LinearLossFunction.apply(z, bias, gt_norm_xywh, gt_cls_prob, obj_mask, self,
+                                             global_batch)
+        terms, _, _ = self.loss_fwd_bwd_linear(z, bias, gt_norm_xywh, gt_cls_prob, obj_mask,
+                                               global_batch, want_bias_grad=False)
+        self.last_loss_terms = terms
+        return terms[4]
+
     def get_loss(self, image, gt_norm_xywh, gt_cls_prob, obj_mask, global_batch=None):
         """model.py:296-317: (coord + conf + cls) / B as a 0-d tensor that supports
         ``.backward()``.  ``image`` goes through the attached backbone; without
@@ -375,8 +468,11 @@ class YOLOv1Head(nn.Module):
         return ltrb, score, cls, present.view(torch.bool)
 
     def postprocess(self, out, conf_thresh=0.5, iou_thresh=0.5, mode=_lib.YH_MODE_REFERENCE,
-                    return_idx=False):
+                    return_idx=False, bias: Optional[torch.Tensor] = None):
         """Decode + confidence threshold + per-class NMS in one kernel.
+
+        With ``bias`` (S*S*D floats), ``out`` is the last layer's product before its
+        bias (model.py:133-135) and the bias is added as the kernel reads it.
 
         Returns dets (B, S*S*Bx, 6) with the kept rows ``l, t, r, b, conf, class``
         first (the row layout eval.py:89-91 consumes; class ascending, then
@@ -388,11 +484,15 @@ class YOLOv1Head(nn.Module):
         dets = torch.empty(bsz, nn_, 6, dtype=torch.float32, device=dev)
         count = torch.empty(bsz, dtype=torch.int32, device=dev)
         kidx = torch.empty(bsz, nn_, dtype=torch.int32, device=dev) if return_idx else None
+        tail = (dets.data_ptr(), count.data_ptr(), _ptr(kidx), int(mode), float(conf_thresh),
+                float(iou_thresh), bsz, self.n_cells, self.n_bboxes, self.n_classes, self.img_size,
+                _stream(dev))
         with torch.cuda.device(dev):
-            _lib.check(_lib.load().yh_decode_nms(
-                out.data_ptr(), dets.data_ptr(), count.data_ptr(), _ptr(kidx), int(mode),
-                float(conf_thresh), float(iou_thresh), bsz, self.n_cells, self.n_bboxes,
-                self.n_classes, self.img_size, _stream(dev)))
+            if bias is None:
+                _lib.check(_lib.load().yh_decode_nms(out.data_ptr(), *tail))
+            else:
+                bias = self._check_bias(bias, dev)
+                _lib.check(_lib.load().yh_decode_nms_linear(out.data_ptr(), bias.data_ptr(), *tail))
         return (dets, count, kidx) if return_idx else (dets, count)
 
     @staticmethod
