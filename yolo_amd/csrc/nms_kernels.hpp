@@ -44,7 +44,7 @@ struct NmsArgs {
     int nout;   // rows of dets per image
     float cellf, imgf, conf_thr, iou_thr;
     // per-image LDS region: byte offsets of the arrays inside it, and its size
-    int off_keys, off_box, off_meta, off_alive, off_misc, off_ccls, off_hist, off_segst;
+    int off_keys, off_box, off_meta, off_alive, off_misc, off_ccls, off_hist, off_segst, off_pair;
     int region_bytes;
     int dbg_stop;  // builds with -DYH_PHASE_PROBE only: leave after this phase (0 = run everything)
 };
@@ -148,6 +148,7 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
     constexpr bool kBias = SRC == 2;               // ... to which a bias is added on the way in
     // class-bucketed ranking: a workgroup per image, class count known and bounded
     constexpr bool kBucket = NT != 64 && kHead;
+    constexpr bool kWave = NT == 64;               // one wavefront per image
     constexpr int NW = NT / 64;          // wavefronts per image
     const int sub = threadIdx.x / NT;
     const int t = threadIdx.x % NT;
@@ -298,13 +299,33 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
         clsbase[e] = (unsigned long long)(unsigned int)ccl[e] << 48;
         key[e] = cvalid[e] ? (clsbase[e] | ((unsigned long long)sk << 16) | (unsigned int)n)
                            : ~0ull;
-        if constexpr (!kBucket) keys[n] = key[e];
+        if constexpr (!kBucket && !kWave) keys[n] = key[e];
+    }
+    int nvalid_w = 0;   // kWave: valid candidates of the image (wave-uniform)
+    if constexpr (kWave) {
+        // only valid candidates are ranked: their keys go to the front of the array
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            const unsigned long long vm = __ballot(cvalid[e]);
+            if (cvalid[e]) keys[nvalid_w + __popcll(vm & ((1ull << lane) - 1ull))] = key[e];
+            nvalid_w += __popcll(vm);
+        }
     }
     group_sync<NT>();
     int rank[ITEMS], seg[ITEMS];
 #pragma unroll
     for (int e = 0; e < ITEMS; ++e) { rank[e] = 0; seg[e] = 0; }
-    if constexpr (kBucket) {
+    if constexpr (kWave) {
+        // every lane reads the same LDS address per iteration (a broadcast); unrolled
+        // so that several reads are in flight.  The class segment starts are found
+        // after the scatter, from the sorted order itself.
+#pragma unroll 8
+        for (int j = 0; j < nvalid_w; ++j) {
+            const unsigned long long kj = keys[j];
+#pragma unroll
+            for (int e = 0; e < ITEMS; ++e) rank[e] += kj < key[e] ? 1 : 0;
+        }
+    } else if constexpr (kBucket) {
         // Many candidates per image: bucket them by class first, so that a candidate
         // is ranked against the members of its own class only (N * segment length
         // comparisons instead of N * N).
@@ -362,8 +383,6 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
             }
         }
     } else {
-        // every lane reads the same LDS address per iteration (a broadcast); unrolled
-        // so that several reads are in flight
 #pragma unroll 8
         for (int j = 0; j < nslot; ++j) {
             const unsigned long long kj = keys[j];
@@ -387,16 +406,18 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
             smeta[rank[e]] = make_int4(__float_as_int(cscore[e]), ccl[e], cidx[e], seg[e]);
             mp_local = max(mp_local, rank[e] - seg[e]);
         }
-        nv_local += __popcll(__ballot(cvalid[e]));
+        if constexpr (!kWave) nv_local += __popcll(__ballot(cvalid[e]));
     }
-    mp_local = wave_max(mp_local);
-    if (lane == 0) {
-        atomicAdd(&misc[0], nv_local);
-        atomicMax(&misc[1], mp_local);
+    if constexpr (!kWave) {
+        mp_local = wave_max(mp_local);
+        if (lane == 0) {
+            atomicAdd(&misc[0], nv_local);
+            atomicMax(&misc[1], mp_local);
+        }
     }
     group_sync<NT>();
-    const int nvalid = misc[0];
-    const int maxpos = misc[1];
+    const int nvalid = kWave ? nvalid_w : misc[0];
+    int maxpos = kWave ? 0 : misc[1];
 
 #ifdef YH_PHASE_PROBE
     if (a.dbg_stop == 3) return;
@@ -416,6 +437,32 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
             mybox[e] = {b.x, b.y, b.z, b.w};
             mymeta[e] = smeta[i];
         }
+    }
+    if constexpr (kWave) {
+        // Lane = sorted position: a class segment starts where the class changes, so
+        // the start of my segment is the highest such position at or below mine.
+        unsigned long long heads[ITEMS];
+        int prev_last = -1;   // class of the last position of the previous item
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            const int c = mymeta[e].y;
+            int pc = __shfl_up(c, 1, 64);
+            if (lane == 0) pc = prev_last;
+            heads[e] = __ballot(al[e] && (e * NT + lane == 0 || c != pc));
+            prev_last = __shfl(c, 63, 64);
+        }
+        int mp = 0;
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            const unsigned long long mine = heads[e] & ((2ull << lane) - 1ull);
+            int sg = mine ? e * NT + 63 - __clzll(mine) : -1;
+#pragma unroll
+            for (int q = ITEMS - 1; q >= 0; --q)
+                if (q < e && sg < 0 && heads[q]) sg = q * NT + 63 - __clzll(heads[q]);
+            mymeta[e].w = al[e] ? sg : 0;
+            mp = max(mp, al[e] ? e * NT + lane - sg : 0);
+        }
+        maxpos = wave_max(mp);
     }
     int pos_out[ITEMS];   // output row of a survivor
     int total = 0;        // survivors of the image
@@ -447,6 +494,131 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
         for (int e = 0; e < ITEMS; ++e) {
             pos_out[e] = total + __popcll(aw[e] & ((1ull << lane) - 1ull));
             total += __popcll(aw[e]);
+        }
+    } else if (maxpos < 64) {
+        // A workgroup per image, no class segment longer than 64.  The pairs
+        // (earlier member i, later member p) of all segments are spread evenly over
+        // the threads, whatever the segment lengths; a pair whose IoU exceeds the
+        // threshold sets bit (index of p in the segment) in the word of i.  One lane
+        // per segment then walks its members in order: a member still alive kills
+        // the members in its word.  No barrier per member, and every lane of the
+        // pair loop has work.
+        unsigned long long* kills = keys;     // the keys are not needed any more
+        int* poff = reinterpret_cast<int*>(region + a.off_pair);   // pairs before position p
+        int* ctot = poff + NT * ITEMS + 1;                           // pairs per chunk of 64
+        int r[ITEMS], excl[ITEMS];
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            const int i = e * NT + t;
+            r[e] = al[e] ? i - mymeta[e].w : 0;   // members of my segment ahead of me
+            int incl = r[e];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += up;
+            }
+            excl[e] = incl - r[e];
+            if (lane == 63) ctot[e * NW + wv] = incl;
+            if (al[e]) kills[i] = 0ull;
+        }
+        if (t == 0) misc[2] = 0;   // number of segment heads queued below
+        group_sync<NT>();
+        int npairs = 0;
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            int carry = 0;
+#pragma unroll
+            for (int q = 0; q < ITEMS * NW; ++q) {
+                const int v = ctot[q];
+                if (q < e * NW + wv) carry += v;
+                npairs += e == 0 ? v : 0;
+            }
+            if (al[e]) poff[e * NT + t] = carry + excl[e];
+        }
+        group_sync<NT>();
+#ifdef YH_PHASE_PROBE
+        if (a.dbg_stop == 5) return;
+#endif
+        const int per = (npairs + NT - 1) / NT;
+        int k = t * per;
+        const int kend = min(npairs, k + per);
+        if (k < kend) {
+            // last position whose offset is <= k: the later member of pair k
+            int lo = 0, hi = nvalid - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (poff[mid] <= k) lo = mid; else hi = mid - 1;
+            }
+            int p = lo;
+            int4 mp = smeta[p];
+            float4 bp = sbox[p];
+            int ii = k - poff[p];                 // index of the earlier member in the segment
+            float4 b = sbox[mp.w + ii];
+            for (; k < kend; ++k) {
+                // state of the next pair first, so that its box is in flight during the IoU
+                const int cur_i = mp.w + ii, cur_bit = p - mp.w;
+                const float4 cb = b, cbp = bp;
+                if (k + 1 < kend) {
+                    if (++ii == p - mp.w) {
+                        do { ++p; mp = smeta[p]; } while (p == mp.w);   // segment heads own no pair
+                        bp = sbox[p];
+                        ii = 0;
+                    }
+                    b = sbox[mp.w + ii];
+                }
+                if (iou_pair({cb.x, cb.y, cb.z, cb.w}, {cbp.x, cbp.y, cbp.z, cbp.w}) > a.iou_thr)
+                    atomicOr(&kills[cur_i], 1ull << cur_bit);
+            }
+        }
+        group_sync<NT>();
+#ifdef YH_PHASE_PROBE
+        if (a.dbg_stop == 6) return;
+#endif
+        // segment lengths, left at the head's slot of the (now free) offset array;
+        // the heads queue up in a list (any order: segments are independent)
+        int* hlist = reinterpret_cast<int*>(sbox);   // every box is in registers by now
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            const int i = e * NT + t;
+            if (al[e]) {
+                const int nxt = i + 1 < nvalid ? smeta[i + 1].w : -1;
+                if (nxt != mymeta[e].w) poff[mymeta[e].w] = r[e] + 1;
+                if (r[e] == 0) hlist[atomicAdd(&misc[2], 1)] = i;
+            }
+        }
+        group_sync<NT>();
+        // one lane per segment: greedy pass over its members, eight words per round trip
+        const int nheads = misc[2];
+        for (int h = t; h < nheads; h += NT) {
+            const int head = hlist[h];
+            const int len = poff[head];
+            unsigned long long dead = 0ull;
+            for (int base = 0; base < len; base += 8) {
+                unsigned long long kw[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) kw[u] = base + u < len ? kills[head + base + u] : 0ull;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (!((dead >> (base + u)) & 1ull)) dead |= kw[u];
+            }
+            kills[head] = dead;
+        }
+        group_sync<NT>();
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            if (al[e] && ((kills[mymeta[e].w] >> r[e]) & 1ull)) al[e] = false;
+            const unsigned long long w = __ballot(al[e]);
+            if (lane == 0) alive[e * NW + wv] = w;
+        }
+        group_sync<NT>();
+#pragma unroll
+        for (int w = 0; w < ITEMS * NW; ++w) total += __popcll(alive[w]);
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            const int myw = e * NW + wv;
+            int pos = __popcll(alive[myw] & ((1ull << lane) - 1ull));
+            for (int w = 0; w < myw; ++w) pos += __popcll(alive[w]);
+            pos_out[e] = pos;
         }
     } else {
 #pragma unroll

@@ -63,6 +63,8 @@ void nms_layout(yh::NmsArgs& a, int slot_pad) {
     off += round16(a.nc * 4);
     a.off_segst = off;
     off += round16(a.nc * 4);
+    a.off_pair = off;     // pair offsets per position + per-chunk totals (a workgroup per image)
+    off += slot_pad > 128 ? round16((slot_pad + 1 + 16) * 4) : 0;
     a.region_bytes = off;
 }
 
