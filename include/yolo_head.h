@@ -249,6 +249,31 @@ int yh_decode_grid(const float* pred, float* ltrb, float* conf, float* cls_prob,
                    void* stream);
 
 /*
+ * The box helpers of the reference as stand-alone element-wise kernels, for code
+ * that calls them one by one (the fused entry points above do not go through
+ * them).  Boxes are float4, 16-byte aligned.
+ * yh_norm_xywh: get_norm_xywh (model.py:157-165) batched: norm_xywh
+ *   (batch, S*S, Bx, 4) = sigmoid of channels 5k .. 5k+3 of cell i*S + j.
+ * yh_denormalize_xywh: denormalize_xywh (model.py:167-183) on (batch, S*S, Bx, 4):
+ *   x, y times the cell size plus the cell's offset (first grid index carries x),
+ *   w, h times the image size.
+ * yh_xywh_to_ltrb: xywh_to_ltrb (model.py:150-155) on n boxes, with the
+ *   reference's one-sided clips (l, t at 0 from below; r, b at img_size from above).
+ * yh_responsibility_mask: _get_responsibility_mask (model.py:190-211) as get_loss
+ *   needs it: resp_mask (batch, S*S, Bx) u8 is 1 for the predictor with the highest
+ *   IoU against the ground truth of a cell that holds an object (first index on
+ *   ties), 0 elsewhere -- the mask yh_loss_fwd_bwd works with internally.
+ */
+int yh_norm_xywh(const float* pred, float* norm_xywh, int64_t batch, int S, int Bx, int C,
+                 void* stream);
+int yh_denormalize_xywh(const float* norm_xywh, float* xywh, int64_t batch, int S, int Bx,
+                        int img_size, void* stream);
+int yh_xywh_to_ltrb(const float* xywh, float* ltrb, int64_t n, int img_size, void* stream);
+int yh_responsibility_mask(const float* pred, const float* gt_xywh, const uint8_t* obj_mask,
+                           uint8_t* resp_mask, int64_t batch, int S, int Bx, int C, int img_size,
+                           void* stream);
+
+/*
  * NMS candidates exactly as yh_decode_nms forms them internally (same device
  * code): flat index n = cell*Bx + k, N = S*S*Bx per image.
  *   cand_ltrb (batch, N, 4), cand_score (batch, N) = confidence,

@@ -79,6 +79,11 @@ SIGNATURES = {
     "yh_decode_grid": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_float, c_int64, c_int, c_int, c_int, c_int,
                                c_void_p]),
+    "yh_norm_xywh": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "yh_denormalize_xywh": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "yh_xywh_to_ltrb": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "yh_responsibility_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                       c_int, c_int, c_int, c_void_p]),
     "yh_decode_candidates": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "yh_decode_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,

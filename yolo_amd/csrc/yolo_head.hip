@@ -47,6 +47,14 @@ inline int launch_status() {
 
 inline int round16(int x) { return (x + 15) & ~15; }
 
+// workgroups of 256 threads for an elementwise kernel with a grid-stride loop
+inline unsigned grid_for(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > (1 << 20)) b = 1 << 20;
+    return (unsigned)b;
+}
+
 // LDS layout of one image's region in nms_kernel
 void nms_layout(yh::NmsArgs& a, int slot_pad) {
     a.off_keys = 0;
@@ -478,6 +486,53 @@ int yh_decode_grid(const float* pred, float* ltrb, float* conf, float* cls_prob,
     hipLaunchKernelGGL(yh::decode_grid_kernel, dim3((unsigned)blocks), dim3(256), 0,
                        (hipStream_t)stream, pred, ltrb, conf, cls_prob, (long long*)cls_idx,
                        (long long*)best_k, best_ltrb, conf_mask, conf_thresh, (long long)batch,
+                       S, Bx, C, (float)(img_size / S), (float)img_size);
+    return launch_status();
+}
+
+int yh_norm_xywh(const float* pred, float* norm_xywh, int64_t batch, int S, int Bx, int C,
+                 void* stream) {
+    if (const int rc = check_shape(batch, S, Bx, C, S)) return rc;
+    if (batch == 0) return YH_OK;
+    if (!pred || !norm_xywh) return YH_ERR_NULL;
+    if (!aligned(pred, 4) || !aligned(norm_xywh, 16)) return YH_ERR_ALIGN;
+    hipLaunchKernelGGL(yh::norm_xywh_kernel, dim3(grid_for(batch * S * S)), dim3(256), 0,
+                       (hipStream_t)stream, pred, norm_xywh, (long long)batch, S, Bx, C);
+    return launch_status();
+}
+
+int yh_denormalize_xywh(const float* norm_xywh, float* xywh, int64_t batch, int S, int Bx,
+                        int img_size, void* stream) {
+    if (const int rc = check_shape(batch, S, Bx, 1, img_size)) return rc;
+    if (batch == 0) return YH_OK;
+    if (!norm_xywh || !xywh) return YH_ERR_NULL;
+    if (!aligned(norm_xywh, 16) || !aligned(xywh, 16)) return YH_ERR_ALIGN;
+    const int64_t n = batch * S * S * Bx;
+    hipLaunchKernelGGL(yh::denormalize_xywh_kernel, dim3(grid_for(n)), dim3(256), 0,
+                       (hipStream_t)stream, norm_xywh, xywh, (long long)n, S, Bx,
+                       (float)(img_size / S), (float)img_size);
+    return launch_status();
+}
+
+int yh_xywh_to_ltrb(const float* xywh, float* ltrb, int64_t n, int img_size, void* stream) {
+    if (n < 0 || img_size < 1) return YH_ERR_SHAPE;
+    if (n == 0) return YH_OK;
+    if (!xywh || !ltrb) return YH_ERR_NULL;
+    if (!aligned(xywh, 16) || !aligned(ltrb, 16)) return YH_ERR_ALIGN;
+    hipLaunchKernelGGL(yh::xywh_to_ltrb_kernel, dim3(grid_for(n)), dim3(256), 0,
+                       (hipStream_t)stream, xywh, ltrb, (long long)n, (float)img_size);
+    return launch_status();
+}
+
+int yh_responsibility_mask(const float* pred, const float* gt_xywh, const uint8_t* obj_mask,
+                           uint8_t* resp_mask, int64_t batch, int S, int Bx, int C, int img_size,
+                           void* stream) {
+    if (const int rc = check_shape(batch, S, Bx, C, img_size)) return rc;
+    if (batch == 0) return YH_OK;
+    if (!pred || !gt_xywh || !obj_mask || !resp_mask) return YH_ERR_NULL;
+    if (!aligned(pred, 4) || !aligned(gt_xywh, 16)) return YH_ERR_ALIGN;
+    hipLaunchKernelGGL(yh::responsibility_mask_kernel, dim3(grid_for(batch * S * S)), dim3(256), 0,
+                       (hipStream_t)stream, pred, gt_xywh, obj_mask, resp_mask, (long long)batch,
                        S, Bx, C, (float)(img_size / S), (float)img_size);
     return launch_status();
 }

@@ -430,6 +430,93 @@ class YOLOv1Head(nn.Module):
         """model.py:185-188, batched: (B, S*S, Bx, 4) pixel boxes."""
         return self._decode(out, ("ltrb",))["ltrb"]
 
+    def get_norm_xywh(self, out):
+        """model.py:157-165, batched: (B, S*S, Bx, 4) sigmoid of the box channels,
+        cell index i*S + j."""
+        out = self._check_out(out.detach())
+        res = torch.empty(out.shape[0], self.n_grid, self.n_bboxes, 4, dtype=torch.float32,
+                          device=out.device)
+        with torch.cuda.device(out.device):
+            _lib.check(_lib.load().yh_norm_xywh(out.data_ptr(), res.data_ptr(), out.shape[0],
+                                                self.n_cells, self.n_bboxes, self.n_classes,
+                                                _stream(out.device)))
+        return res
+
+    def denormalize_xywh(self, norm_xywh):
+        """model.py:167-183 on (B, S*S, K, 4) (or (S*S, K, 4) for one image): pixels,
+        the first grid index carries x."""
+        _need(norm_xywh, "norm_xywh", torch.float32)
+        shape = norm_xywh.shape
+        if norm_xywh.dim() not in (3, 4) or shape[-1] != 4 or shape[-3] != self.n_grid:
+            raise ValueError(f"norm_xywh: expected (B, {self.n_grid}, K, 4), got {tuple(shape)}")
+        bsz = shape[0] if norm_xywh.dim() == 4 else 1
+        res = torch.empty_like(norm_xywh)
+        with torch.cuda.device(norm_xywh.device):
+            _lib.check(_lib.load().yh_denormalize_xywh(
+                norm_xywh.data_ptr(), res.data_ptr(), bsz, self.n_cells, shape[-2], self.img_size,
+                _stream(norm_xywh.device)))
+        return res
+
+    def xywh_to_ltrb(self, xywh):
+        """model.py:150-155 on (..., 4): one-sided clips at 0 and img_size."""
+        _need(xywh, "xywh", torch.float32)
+        if xywh.shape[-1] != 4:
+            raise ValueError(f"xywh: expected (..., 4), got {tuple(xywh.shape)}")
+        res = torch.empty_like(xywh)
+        with torch.cuda.device(xywh.device):
+            _lib.check(_lib.load().yh_xywh_to_ltrb(xywh.data_ptr(), res.data_ptr(),
+                                                   xywh.numel() // 4, self.img_size,
+                                                   _stream(xywh.device)))
+        return res
+
+    def _get_responsibility_mask(self, out, gt_norm_xywh, obj_mask):
+        """model.py:190-211 as get_loss needs it: (B, S*S, Bx, 1) bool, True for the
+        predictor with the highest IoU against the ground truth of a cell that
+        holds an object (first index on ties)."""
+        out = self._check_out(out.detach())
+        bsz, n = out.shape[0], self.n_grid
+        _need(gt_norm_xywh, "gt_norm_xywh", torch.float32, (bsz, n, 1, 4))
+        if obj_mask.dtype == torch.bool:
+            obj_mask = obj_mask.view(torch.uint8)
+        _need(obj_mask, "obj_mask", torch.uint8, (bsz, n, 1, 1))
+        res = torch.empty(bsz, n, self.n_bboxes, 1, dtype=torch.uint8, device=out.device)
+        with torch.cuda.device(out.device):
+            _lib.check(_lib.load().yh_responsibility_mask(
+                out.data_ptr(), gt_norm_xywh.data_ptr(), obj_mask.data_ptr(), res.data_ptr(), bsz,
+                self.n_cells, self.n_bboxes, self.n_classes, self.img_size, _stream(out.device)))
+        return res.view(torch.bool)
+
+    def get_object_mask(self, gt_ltrb):
+        """model.py:213-222: (S, S) bool grid of one image's boxes (M, 4), indexed
+        [x_cell, y_cell]."""
+        _need(gt_ltrb, "gt_ltrb", torch.float32)
+        m = gt_ltrb.shape[0]
+        if m == 0:
+            return torch.zeros(self.n_cells, self.n_cells, dtype=torch.bool, device=gt_ltrb.device)
+        label = torch.zeros(1, m, dtype=torch.int32, device=gt_ltrb.device)
+        count = torch.full((1,), m, dtype=torch.int32, device=gt_ltrb.device)
+        _, _, om = self.encode_targets(gt_ltrb.view(1, m, 4), label, count)
+        return om.view(self.n_cells, self.n_cells)
+
+    def get_loss_terms(self, out, gt_norm_xywh, gt_cls_prob, obj_mask):
+        """The three sums get_loss adds (model.py:311-313), undivided: coordinate,
+        confidence, classification.  Values only; gradients flow through get_loss."""
+        terms, _ = self._launch_loss(self._check_out(out.detach()), gt_norm_xywh, gt_cls_prob,
+                                     obj_mask, 1.0)
+        return terms[0], terms[1], terms[2]
+
+    def get_coordinate_loss(self, out, gt_norm_xywh, gt_cls_prob, obj_mask):
+        """model.py:224-240 (the arguments are those get_loss has in scope)."""
+        return self.get_loss_terms(out, gt_norm_xywh, gt_cls_prob, obj_mask)[0]
+
+    def get_confidence_loss(self, out, gt_norm_xywh, gt_cls_prob, obj_mask):
+        """model.py:252-276."""
+        return self.get_loss_terms(out, gt_norm_xywh, gt_cls_prob, obj_mask)[1]
+
+    def get_classification_loss(self, out, gt_norm_xywh, gt_cls_prob, obj_mask):
+        """model.py:288-294."""
+        return self.get_loss_terms(out, gt_norm_xywh, gt_cls_prob, obj_mask)[2]
+
     def get_confidence(self, out):
         """model.py:242-250: (B, S*S, Bx, 1)."""
         return self._decode(out, ("conf",))["conf"]
