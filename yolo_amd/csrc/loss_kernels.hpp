@@ -16,6 +16,44 @@ constexpr int LOSS_THREADS = 256;
 // A cell without object: only the no-object confidence term (model.py:270-274);
 // every other gradient of the cell is zero.  `logit(ch)` returns channel ch of
 // the cell, `g` points at the cell's gradient (channels S2 floats apart).
+// loss_noobj_cell for run-time predictor and class counts: the confidence logits
+// are fetched four at a time and the zero stores are written out eight per
+// iteration (a rolled loop costs an address computation and a branch per store).
+template <class L>
+__device__ __forceinline__ void loss_noobj_cell_rt(const L& logit, float* __restrict__ g, int S2,
+                                                   int nb, int nc, float ln, float inv_gb,
+                                                   float& acc_conf) {
+    for (int k0 = 0; k0 < nb; k0 += 4) {
+        float c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = k0 + u < nb ? logit(5 * (k0 + u) + 4) : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k0 + u < nb) {
+                const float conf = sigmoidf_(c[u]);
+                acc_conf += ln * (conf * conf);
+                float* q = g + (size_t)(5 * (k0 + u)) * S2;
+                q[0] = 0.0f;
+                q[S2] = 0.0f;
+                q[2 * S2] = 0.0f;
+                q[3 * S2] = 0.0f;
+                q[4 * S2] = 2.0f * ln * conf * (conf * (1.0f - conf)) * inv_gb;
+            }
+        }
+    }
+    float* q = g + (size_t)(5 * nb) * S2;
+    int j = 0;
+    for (; j + 8 <= nc; j += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u * S2] = 0.0f;
+        q += 8 * (size_t)S2;
+    }
+    for (; j < nc; ++j) {
+        *q = 0.0f;
+        q += S2;
+    }
+}
+
 template <class L>
 __device__ __forceinline__ void loss_noobj_cell(const L& logit, float* __restrict__ g, int S2,
                                                 int nb, int nc, float ln, float inv_gb,
@@ -137,8 +175,16 @@ __device__ __forceinline__ void loss_obj_cell(const L& logit, float* __restrict_
 #pragma unroll
         for (int j = 1; j < C_CT; ++j) m = fmaxf(m, logit(c0 + j));
     } else {
-#pragma unroll 8
-        for (int j = 1; j < nc; ++j) m = fmaxf(m, logit(c0 + j));
+        // run-time class count: eight classes per batch, written out so that the
+        // eight loads of a batch are in flight together (one round trip per batch,
+        // not per class); sums run in class order, as in the compile-time path
+        for (int j0 = 1; j0 < nc; j0 += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = j0 + u < nc ? logit(c0 + j0 + u) : m;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m = fmaxf(m, t[u]);
+        }
     }
     float s = 0.f, dot = 0.f, l2 = 0.f;
     if constexpr (C_CT > 0) {
@@ -161,22 +207,46 @@ __device__ __forceinline__ void loss_obj_cell(const L& logit, float* __restrict_
         for (int j = 0; j < C_CT; ++j)
             g[(c0 + j) * S2] = e[j] * (2.0f * (e[j] - gtcls(j)) - dot) * inv_gb;
     } else {
-        // run-time class count: unrolled by 8 so that eight loads are in flight per
-        // round trip instead of one
-#pragma unroll 8
-        for (int j = 0; j < nc; ++j) s += exp_fast(logit(c0 + j) - m);
-        const float rs = rcp_fast(s);
-#pragma unroll 8
-        for (int j = 0; j < nc; ++j) {
-            const float pj = exp_fast(logit(c0 + j) - m) * rs;
-            const float d = pj - gtcls(j);
-            l2 += d * d;
-            dot += 2.0f * d * pj;
+        for (int j0 = 0; j0 < nc; j0 += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = j0 + u < nc ? logit(c0 + j0 + u) : m;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 + u < nc) s += exp_fast(t[u] - m);
         }
-#pragma unroll 8
-        for (int j = 0; j < nc; ++j) {
-            const float pj = exp_fast(logit(c0 + j) - m) * rs;
-            g[(c0 + j) * S2] = pj * (2.0f * (pj - gtcls(j)) - dot) * inv_gb;
+        const float rs = rcp_fast(s);
+        for (int j0 = 0; j0 < nc; j0 += 8) {
+            float t[8], q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                t[u] = j0 + u < nc ? logit(c0 + j0 + u) : m;
+                q[u] = j0 + u < nc ? gtcls(j0 + u) : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (j0 + u < nc) {
+                    const float pj = exp_fast(t[u] - m) * rs;
+                    const float d = pj - q[u];
+                    l2 += d * d;
+                    dot += 2.0f * d * pj;
+                }
+            }
+        }
+        for (int j0 = 0; j0 < nc; j0 += 8) {
+            float t[8], q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                t[u] = j0 + u < nc ? logit(c0 + j0 + u) : m;
+                q[u] = j0 + u < nc ? gtcls(j0 + u) : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (j0 + u < nc) {
+                    const float pj = exp_fast(t[u] - m) * rs;
+                    g[(c0 + j0 + u) * S2] = pj * (2.0f * (pj - q[u]) - dot) * inv_gb;
+                }
+            }
         }
     }
     acc_cls += l2;
@@ -351,7 +421,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
                                  S, S2, nb, nc, cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf,
                                  acc_cls);
             else
-                loss_noobj_cell(logit, grad + off, S2, nb, nc, ln, inv_gb, acc_conf);
+                loss_noobj_cell_rt(logit, grad + off, S2, nb, nc, ln, inv_gb, acc_conf);
         }
     }
     loss_block_reduce(acc_coord, acc_conf, acc_cls, partials, bid);
