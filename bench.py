@@ -57,7 +57,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--batch", type=int, default=4096, help="images per GPU")
-    ap.add_argument("--allreduce-every", type=int, default=32)
+    ap.add_argument("--allreduce-every", type=int, default=128,
+                    help="steps whose loss sums share one all-reduce (the ring copy happens for one GPU too)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--steps-per-graph", type=int, default=16,
                     help="steps captured into one HIP graph (the remainder of --steps runs on a 1-step graph)")
