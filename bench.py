@@ -243,7 +243,8 @@ def main():
                     graphs[("loss", unit)].replay()
                 with torch.cuda.stream(s_nms):
                     graphs[("nms", unit)].replay()
-            if rest % unit:                          # one odd step: eagerly, then restart the halves
+            if rest % unit:                          # one odd step: eagerly, between two flushes --
+                loss_flush()                         # the replays moved on without the head's phase count
                 with torch.cuda.stream(s_loss):
                     loss_step()
                 with torch.cuda.stream(s_nms):
@@ -318,6 +319,9 @@ def main():
     loss_value = float(losses[-1, 3].item()) / global_batch
     if not torch.isfinite(losses).all():
         raise SystemExit("non-finite loss in the timed region")
+    # every step saw the same resident batch: a row that differs was lost or logged twice
+    if not torch.equal(losses, losses[:1].expand_as(losses)):
+        raise SystemExit("the per-step loss log is not the same row for every step")
 
     value = args.steps * global_batch / elapsed
     result = {

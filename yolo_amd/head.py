@@ -243,7 +243,9 @@ class YOLOv1Head(nn.Module):
         ``terms_prev`` (5 floats) receives the previous step's terms.
 
         The calls alternate between the two halves of a workspace the head keeps
-        per device; capture an even number of them when building a HIP graph."""
+        per device; capture an even number of them when building a HIP graph.  The
+        head counts the phases of the calls it sees: replays of a captured graph are
+        not among them, so call ``flush_loss_log`` between replays and eager calls."""
         out = self._check_out(out.detach())
         bsz, n = out.shape[0], self.n_grid
         _need(gt_norm_xywh, "gt_norm_xywh", torch.float32, (bsz, n, 1, 4))
