@@ -10,7 +10,7 @@ def timeit(fn, iters=200):
     for _ in range(iters): fn()
     b.record(); torch.cuda.synchronize()
     return 1e3 * a.elapsed_time(b) / iters
-for total_mb in (33.7, 52.0, 67.6, 135.0, 540.0):
+for total_mb in (33.7, 52.0, 67.6, 135.0, 540.0, 2000.0, 8000.0):
     n = int(total_mb * 1e6 / 2 / 4)
     x = torch.randn(n, device=dev); y = torch.empty_like(x)
     us = timeit(lambda: y.copy_(x))

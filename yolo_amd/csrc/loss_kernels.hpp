@@ -452,8 +452,18 @@ __global__ __launch_bounds__(LOSS_THREADS, 4) void loss_fwd_bwd_kernel(
     }
     constexpr int D = 5 * BX + C;
     constexpr int S2 = S * S;
-    const long long img0 = (long long)bid * imgs_per_block;
-    const int nitems = imgs_per_block * S2;
+    constexpr int IPB = LOSS_THREADS / S2;      // images per workgroup (the host's choice too)
+    const long long img0 = (long long)bid * IPB;
+    const int nitems = IPB * S2;
+    (void)imgs_per_block;
+    // The workgroup's gradients are one contiguous block of the tensor.  The lanes
+    // leave theirs in LDS and the block goes out in 16-byte stores, whole cache
+    // lines per wavefront instruction, instead of 30 four-byte stores per lane in
+    // runs of S*S floats.  `pad` lines the LDS copy up with the 16-byte grid of
+    // the global addresses.
+    __shared__ __attribute__((aligned(16))) float sgrad[IPB * D * S2 + 4];
+    const long long gbase = img0 * (long long)D * S2;
+    const int pad = (int)(gbase & 3);
 
     float acc_coord = 0.f, acc_conf = 0.f, acc_cls = 0.f;
     for (int item = threadIdx.x; item < nitems; item += LOSS_THREADS) {
@@ -463,6 +473,7 @@ __global__ __launch_bounds__(LOSS_THREADS, 4) void loss_fwd_bwd_kernel(
         if (img < batch) {
             const long long tcell = img * S2 + cell;
             const long long off = img * (long long)D * S2 + cell;
+            float* gl = sgrad + pad + gi * (D * S2) + cell;
             const float* p = pred + off;
             float v[D];
 #pragma unroll
@@ -474,14 +485,28 @@ __global__ __launch_bounds__(LOSS_THREADS, 4) void loss_fwd_bwd_kernel(
             }
             auto logit = [&](int ch) -> float { return v[ch]; };
             if (obj_mask[tcell] != 0)
-                loss_obj_cell<C>(logit, grad + off, gt_xywh + tcell * 4, gt_cls + tcell * C, cell,
+                loss_obj_cell<C>(logit, gl, gt_xywh + tcell * 4, gt_cls + tcell * C, cell,
                                  S, S2, BX, C, cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf,
                                  acc_cls);
             else
-                loss_noobj_cell(logit, grad + off, S2, BX, C, ln, inv_gb, acc_conf);
+                loss_noobj_cell(logit, gl, S2, BX, C, ln, inv_gb, acc_conf);
         }
     }
-    loss_block_reduce(acc_coord, acc_conf, acc_cls, partials, bid);
+    loss_block_reduce(acc_coord, acc_conf, acc_cls, partials, bid);   // has a barrier after the LDS writes
+    {
+        const long long left = batch - img0;
+        const int n = (int)(left < IPB ? left : IPB) * (D * S2);   // floats of this block
+        float* gout = grad + gbase;
+        const int head = (4 - pad) & 3;                             // floats up to the 16-byte grid
+        if ((int)threadIdx.x < head && (int)threadIdx.x < n)
+            gout[threadIdx.x] = sgrad[pad + threadIdx.x];
+        const int n4 = n > head ? (n - head) >> 2 : 0;
+        const float4* s4 = reinterpret_cast<const float4*>(sgrad + pad + head);
+        float4* g4 = reinterpret_cast<float4*>(gout + head);
+        for (int i = threadIdx.x; i < n4; i += LOSS_THREADS) g4[i] = s4[i];
+        const int done = head + 4 * n4;
+        if ((int)threadIdx.x < n - done) gout[done + threadIdx.x] = sgrad[pad + done + threadIdx.x];
+    }
 }
 
 // One workgroup of LOSS_THREADS threads: adds the rows in a fixed order (fp64

@@ -175,7 +175,7 @@ int loss_launch(const float* pred, const float* bias, const float* gt_xywh, cons
     const float cellf = (float)(img_size / S);
     const float imgf = (float)img_size;
     if (!aligned(bias, 4)) return YH_ERR_ALIGN;
-    const bool fast = S == 7 && Bx == 2 && C == 20 && aligned(gt_cls, 16);
+    const bool fast = S == 7 && Bx == 2 && C == 20 && aligned(gt_cls, 16) && aligned(grad_pred, 16);
     const yh::LossPipe pp = pipe ? *pipe : yh::LossPipe{};
     const dim3 grid((unsigned)(rows + (pipe ? 1 : 0)));
 #define YH_LOSS_LAUNCH(PIPE)                                                                     \
