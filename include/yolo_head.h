@@ -79,7 +79,9 @@ size_t yh_workspace_bytes(int op, int64_t batch, int S, int Bx, int C);
  * loss_terms[5] receives: coordinate, confidence and class SUMS over this
  * batch (not divided), their total, and total * inv_global_batch (the value
  * get_loss returns when inv_global_batch = 1/batch, model.py:317).
- * Alignment: gt_xywh 16 bytes; gt_cls 16 bytes when C % 4 == 0.
+ * Alignment: gt_xywh 16 bytes; pred, grad_pred and gt_cls 4 bytes (the kernel tuned for
+ * S=7, Bx=2, C=20 runs when grad_pred and gt_cls are 16-byte aligned, as any
+ * allocation is; otherwise the run-time-shape kernel does the work).
  * workspace: yh_workspace_bytes(YH_OP_LOSS, ...) bytes, 16-byte aligned.
  * The result is bitwise reproducible from run to run (no float atomics).
  */

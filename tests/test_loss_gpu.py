@@ -372,3 +372,33 @@ def test_pipelined_other_shape_and_errors(dev):
     assert lib.yh_loss_pipelined_flush(ws.data_ptr(), ws.numel(), 3, None, None, 0, None, st) == _lib.YH_ERR_ARG
     assert lib.yh_loss_workspace_init(None, 64, st) == _lib.YH_ERR_WORKSPACE
     torch.cuda.synchronize()
+
+
+def test_gradient_buffer_not_16_byte_aligned(dev):
+    """The benchmark-shape kernel stores its gradients in 16-byte units; a gradient
+    buffer that is only 4-byte aligned (legal by the header) takes the run-time-shape
+    kernel instead and must give the same result."""
+    from yolo_amd import _lib
+    lib = _lib.load()
+    batch = 37
+    pred, gx, gc, om = (x.to(dev) for x in synth.make_inputs(batch, seed=77))
+    om8 = om.view(torch.uint8)
+    ws = torch.empty(lib.yh_workspace_bytes(_lib.YH_OP_LOSS, batch, 7, 2, 20), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for shift in (0, 1, 2, 3):
+        buf = torch.full((pred.numel() + 8,), float("nan"), device=dev)
+        grad = buf[shift:shift + pred.numel()]
+        terms = torch.empty(5, device=dev)
+        _lib.check(lib.yh_loss_fwd_bwd(pred.data_ptr(), gx.data_ptr(), gc.data_ptr(), om8.data_ptr(),
+                                       grad.data_ptr(), terms.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       batch, 7, 2, 20, 448, 5.0, 0.5, 1.0 / batch, st))
+        torch.cuda.synchronize()
+        assert torch.isnan(buf[:shift]).all() and torch.isnan(buf[shift + pred.numel():]).all()
+        outs.append((terms.clone(), grad.clone()))
+    ref = ref_cpu.loss_and_grad(pred.cpu(), gx.cpu(), gc.cpu(), om.cpu())
+    for terms, grad in outs:
+        check_against_oracle(terms.cpu(), grad.cpu().view_as(ref["grad"]), ref)
+    scale = outs[0][1].abs().max().item()
+    for terms, grad in outs[1:]:
+        assert (grad - outs[0][1]).abs().max().item() <= 1e-6 * scale
