@@ -465,16 +465,61 @@ __global__ __launch_bounds__(LOSS_THREADS, 4) void loss_fwd_bwd_kernel(
     const long long gbase = img0 * (long long)D * S2;
     const int pad = (int)(gbase & 3);
 
+    // Pass 1, one lane per cell: cells without an object are finished here (two
+    // confidence logits in, their gradients into the tile); cells with one are only
+    // listed, per wavefront, in cell order.  Pass 2: the listed cells -- about 6 %
+    // of all -- are worked on by the first lanes of the workgroup, so the long
+    // object path runs in one wavefront per workgroup instead of in every one.
+    __shared__ int olist[LOSS_THREADS];
+    __shared__ int wcount[LOSS_THREADS / 64];
+    static_assert(IPB * S2 <= LOSS_THREADS, "one cell per lane");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float acc_coord = 0.f, acc_conf = 0.f, acc_cls = 0.f;
-    for (int item = threadIdx.x; item < nitems; item += LOSS_THREADS) {
+    bool has_obj = false;
+    {
+        const int item = threadIdx.x;
         const int gi = item / S2;
         const int cell = item - gi * S2;
         const long long img = img0 + gi;
-        if (img < batch) {
+        if (item < nitems && img < batch) {
             const long long tcell = img * S2 + cell;
-            const long long off = img * (long long)D * S2 + cell;
-            float* gl = sgrad + pad + gi * (D * S2) + cell;
-            const float* p = pred + off;
+            has_obj = obj_mask[tcell] != 0;
+            if (!has_obj) {
+                const float* p = pred + img * (long long)D * S2 + cell;
+                float vc[BX];
+#pragma unroll
+                for (int k = 0; k < BX; ++k) vc[k] = p[(5 * k + 4) * S2];
+                if constexpr (BIAS) {
+#pragma unroll
+                    for (int k = 0; k < BX; ++k) vc[k] += bias[(5 * k + 4) * S2 + cell];
+                }
+                auto logit = [&](int ch) -> float { return vc[ch / 5]; };   // asked for 5k+4 only
+                loss_noobj_cell(logit, sgrad + pad + gi * (D * S2) + cell, S2, BX, C, ln, inv_gb,
+                                acc_conf);
+            }
+        }
+    }
+    const unsigned long long omask = __ballot(has_obj);
+    if (has_obj) olist[wave * 64 + __popcll(omask & ((1ull << lane) - 1ull))] = threadIdx.x;
+    if (lane == 0) wcount[wave] = __popcll(omask);
+    __syncthreads();
+    {
+        int cnt[LOSS_THREADS / 64];
+        int total_obj = 0;
+#pragma unroll
+        for (int q = 0; q < LOSS_THREADS / 64; ++q) { cnt[q] = wcount[q]; total_obj += cnt[q]; }
+        int j = threadIdx.x;
+        if (j < total_obj) {
+            int src = 0;
+#pragma unroll
+            for (int q = 0; q < LOSS_THREADS / 64 - 1; ++q)
+                if (src == q && j >= cnt[q]) { j -= cnt[q]; src = q + 1; }
+            const int item = olist[src * 64 + j];
+            const int gi = item / S2;
+            const int cell = item - gi * S2;
+            const long long img = img0 + gi;
+            const long long tcell = img * S2 + cell;
+            const float* p = pred + img * (long long)D * S2 + cell;
             float v[D];
 #pragma unroll
             for (int ch = 0; ch < D; ++ch) v[ch] = p[ch * S2];
@@ -484,12 +529,9 @@ __global__ __launch_bounds__(LOSS_THREADS, 4) void loss_fwd_bwd_kernel(
                 for (int ch = 0; ch < D; ++ch) v[ch] += bq[ch * S2];
             }
             auto logit = [&](int ch) -> float { return v[ch]; };
-            if (obj_mask[tcell] != 0)
-                loss_obj_cell<C>(logit, gl, gt_xywh + tcell * 4, gt_cls + tcell * C, cell,
-                                 S, S2, BX, C, cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf,
-                                 acc_cls);
-            else
-                loss_noobj_cell(logit, gl, S2, BX, C, ln, inv_gb, acc_conf);
+            loss_obj_cell<C>(logit, sgrad + pad + gi * (D * S2) + cell, gt_xywh + tcell * 4,
+                             gt_cls + tcell * C, cell, S, S2, BX, C, cellf, imgf, lc, ln, inv_gb,
+                             acc_coord, acc_conf, acc_cls);
         }
     }
     loss_block_reduce(acc_coord, acc_conf, acc_cls, partials, bid);   // has a barrier after the LDS writes
