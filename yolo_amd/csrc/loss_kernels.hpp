@@ -427,25 +427,30 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
     loss_block_reduce(acc_coord, acc_conf, acc_cls, partials, bid);
 }
 
-// Compile-time shape.  Every lane fetches the D logits of its cell up front (one
-// memory round trip, independent of obj_mask) and keeps them in registers.  S is
-// a template parameter too: with S*S known, every channel of a cell is a constant
-// byte offset from the cell's address (no per-channel address arithmetic).
-// (Compacting the object cells of a workgroup into one wavefront through LDS was
-// measured slower here: the barriers and the single-wave object path lengthen
-// each workgroup's critical path more than the saved VALU work is worth.)
+// Compile-time shape.  A lane keeps the logits it needs in registers; with S*S
+// known, every channel of a cell is a constant byte offset from the cell's
+// address (no per-channel address arithmetic).
+
+// LDS floats of the gradient tile of one workgroup
+template <int S, int BX, int C>
+constexpr int loss_tile_floats() {
+    return (LOSS_THREADS / (S * S)) * (5 * BX + C) * S * S + 4;
+}
+
+// The work of workgroup `bid` of a grid of `nblocks` (with PIPE, workgroup 0 logs
+// the previous call and the others are this call's rows 0, 1, ...); `sgrad` is an
+// LDS tile of loss_tile_floats() floats, 16-byte aligned.
 template <int S, int BX, int C, bool PIPE, bool BIAS>
-__global__ __launch_bounds__(LOSS_THREADS, 4) void loss_fwd_bwd_kernel(
+__device__ __forceinline__ void loss_block(
     const float* __restrict__ pred, const float* __restrict__ bias,
     const float* __restrict__ gt_xywh,
     const float* __restrict__ gt_cls, const uint8_t* __restrict__ obj_mask,
     float* __restrict__ grad, float* __restrict__ partials, long long batch,
-    int imgs_per_block, float cellf, float imgf, float lc, float ln, float inv_gb,
-    LossPipe pipe) {
-    int bid = blockIdx.x;
+    float cellf, float imgf, float lc, float ln, float inv_gb,
+    const LossPipe& pipe, int bid, int nblocks, float* sgrad) {
     if constexpr (PIPE) {
         if (bid == 0) {
-            loss_pipe_log(pipe, (int)gridDim.x - 1, inv_gb);
+            loss_pipe_log(pipe, nblocks - 1, inv_gb);
             return;
         }
         --bid;
@@ -455,13 +460,11 @@ __global__ __launch_bounds__(LOSS_THREADS, 4) void loss_fwd_bwd_kernel(
     constexpr int IPB = LOSS_THREADS / S2;      // images per workgroup (the host's choice too)
     const long long img0 = (long long)bid * IPB;
     const int nitems = IPB * S2;
-    (void)imgs_per_block;
     // The workgroup's gradients are one contiguous block of the tensor.  The lanes
     // leave theirs in LDS and the block goes out in 16-byte stores, whole cache
     // lines per wavefront instruction, instead of 30 four-byte stores per lane in
     // runs of S*S floats.  `pad` lines the LDS copy up with the 16-byte grid of
     // the global addresses.
-    __shared__ __attribute__((aligned(16))) float sgrad[IPB * D * S2 + 4];
     const long long gbase = img0 * (long long)D * S2;
     const int pad = (int)(gbase & 3);
 
@@ -549,6 +552,21 @@ __global__ __launch_bounds__(LOSS_THREADS, 4) void loss_fwd_bwd_kernel(
         const int done = head + 4 * n4;
         if ((int)threadIdx.x < n - done) gout[done + threadIdx.x] = sgrad[pad + done + threadIdx.x];
     }
+}
+
+template <int S, int BX, int C, bool PIPE, bool BIAS>
+__global__ __launch_bounds__(LOSS_THREADS, 4) void loss_fwd_bwd_kernel(
+    const float* __restrict__ pred, const float* __restrict__ bias,
+    const float* __restrict__ gt_xywh,
+    const float* __restrict__ gt_cls, const uint8_t* __restrict__ obj_mask,
+    float* __restrict__ grad, float* __restrict__ partials, long long batch,
+    int imgs_per_block, float cellf, float imgf, float lc, float ln, float inv_gb,
+    LossPipe pipe) {
+    (void)imgs_per_block;
+    __shared__ __attribute__((aligned(16))) float sgrad[loss_tile_floats<S, BX, C>()];
+    loss_block<S, BX, C, PIPE, BIAS>(pred, bias, gt_xywh, gt_cls, obj_mask, grad, partials, batch,
+                                     cellf, imgf, lc, ln, inv_gb, pipe, (int)blockIdx.x,
+                                     (int)gridDim.x, sgrad);
 }
 
 // One workgroup of LOSS_THREADS threads: adds the rows in a fixed order (fp64

@@ -140,9 +140,10 @@ __device__ __forceinline__ void group_sync() {
 // SRC 0: candidates decoded from the head tensor (S_CT, BX_CT, C_CT > 0: grid
 // size and predictor/class counts fixed at compile time, so every channel of a
 // cell is a constant offset; 0: run-time); SRC 1: candidates loaded from memory.
+// The work of workgroup `block_id` of the NMS grid; `smem` is its LDS
+// (region_bytes per image it holds).
 template <int NT, int ITEMS, int SRC, int S_CT, int BX_CT, int C_CT>
-__global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsigned char* smem) {
     constexpr int IPB = NMS_BLOCK / NT;  // images per workgroup
     constexpr bool kHead = SRC == 0 || SRC == 2;   // candidates decoded from the head tensor
     constexpr bool kBias = SRC == 2;               // ... to which a bias is added on the way in
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
     const int t = threadIdx.x % NT;
     const int lane = threadIdx.x & 63;
     const int wv = t >> 6;  // wavefront within the image group
-    const long long img = (long long)blockIdx.x * IPB + sub;
+    const long long img = (long long)block_id * IPB + sub;
     // NT == 64: a whole wavefront leaves and no workgroup barrier is used below;
     // NT == 256: the grid has exactly one workgroup per image, so this never fires.
     if (img >= a.batch) return;
@@ -682,6 +683,12 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
     if (kd)
         for (int i = total + t; i < nout; i += NT) kd[i] = -1;
     if (t == 0) a.keep_count[img] = total;
+}
+
+template <int NT, int ITEMS, int SRC, int S_CT, int BX_CT, int C_CT>
+__global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    nms_block<NT, ITEMS, SRC, S_CT, BX_CT, C_CT>(a, (int)blockIdx.x, smem);
 }
 
 // ---- candidates to global memory (the values nms_kernel<.,.,0> forms in registers) ---
