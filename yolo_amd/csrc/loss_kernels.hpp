@@ -75,19 +75,20 @@ __device__ __forceinline__ void loss_noobj_cell(const L& logit, float* __restric
 // A cell that holds an object: responsible predictor by IoU, coordinate,
 // objectness, no-object (other predictors) and class terms with all gradients
 // (model.py:190-294 and their autograd backward).  C_CT > 0 with C_CT % 4 == 0:
-// the class targets are fetched as float4 (gcls 16-byte aligned).
-template <int C_CT, class L>
+// the class targets are fetched as float4 (gcls 16-byte aligned).  PART 1 does
+// the box and confidence work of the cell only, PART 2 the class work only (the
+// two touch different channels and different sums), PART 0 both.
+template <int C_CT, int PART = 0, class L>
 __device__ __forceinline__ void loss_obj_cell(const L& logit, float* __restrict__ g,
                                               const float* __restrict__ gxywh,
                                               const float* __restrict__ gcls, int cell, int S,
                                               int S2, int nb, int nc, float cellf, float imgf,
                                               float lc, float ln, float inv_gb, float& acc_coord,
                                               float& acc_conf, float& acc_cls) {
+    constexpr bool kBox = PART != 2, kCls = PART != 1;   // which half of the cell's work
     const int c0 = 5 * nb;
-    // ground truth through the same decode as the predictions (model.py:261-262)
-    const float4 gv = *reinterpret_cast<const float4*>(gxywh);
     float gtc[C_CT > 0 ? C_CT : 1];
-    if constexpr (C_CT > 0 && C_CT % 4 == 0) {
+    if constexpr (kCls && C_CT > 0 && C_CT % 4 == 0) {
 #pragma unroll
         for (int j = 0; j < C_CT / 4; ++j) {
             const float4 q = reinterpret_cast<const float4*>(gcls)[j];
@@ -98,6 +99,9 @@ __device__ __forceinline__ void loss_obj_cell(const L& logit, float* __restrict_
         if constexpr (C_CT > 0 && C_CT % 4 == 0) return gtc[j];
         else return gcls[j];
     };
+    if constexpr (kBox) {
+    // ground truth through the same decode as the predictions (model.py:261-262)
+    const float4 gv = *reinterpret_cast<const float4*>(gxywh);
     const float gnx = gv.x, gny = gv.y, gnw = gv.z, gnh = gv.w;
     const float xoff = cellf * (float)(cell / S);   // first spatial axis carries x (model.py:175-177)
     const float yoff = cellf * (float)(cell % S);
@@ -169,6 +173,8 @@ __device__ __forceinline__ void loss_obj_cell(const L& logit, float* __restrict_
         g[(5 * k + 4) * S2] = gc * inv_gb;
     }
 
+    }   // kBox
+    if constexpr (!kCls) return;
     // class term (model.py:278-294): squared error on the softmax
     float m = logit(c0);
     if constexpr (C_CT > 0) {
@@ -511,8 +517,13 @@ __device__ __forceinline__ void loss_block(
         int total_obj = 0;
 #pragma unroll
         for (int q = 0; q < LOSS_THREADS / 64; ++q) { cnt[q] = wcount[q]; total_obj += cnt[q]; }
-        int j = threadIdx.x;
-        if (j < total_obj) {
+        // the first half of the workgroup does the box and confidence work of the
+        // listed cells, the second half their class work: two wavefronts share what
+        // would be one long path
+        constexpr int HALF = LOSS_THREADS / 2;
+        const bool cls_role = (int)threadIdx.x >= HALF;
+        for (int j0 = (int)threadIdx.x - (cls_role ? HALF : 0); j0 < total_obj; j0 += HALF) {
+            int j = j0;
             int src = 0;
 #pragma unroll
             for (int q = 0; q < LOSS_THREADS / 64 - 1; ++q)
@@ -532,9 +543,13 @@ __device__ __forceinline__ void loss_block(
                 for (int ch = 0; ch < D; ++ch) v[ch] += bq[ch * S2];
             }
             auto logit = [&](int ch) -> float { return v[ch]; };
-            loss_obj_cell<C>(logit, sgrad + pad + gi * (D * S2) + cell, gt_xywh + tcell * 4,
-                             gt_cls + tcell * C, cell, S, S2, BX, C, cellf, imgf, lc, ln, inv_gb,
-                             acc_coord, acc_conf, acc_cls);
+            float* gl = sgrad + pad + gi * (D * S2) + cell;
+            if (cls_role)
+                loss_obj_cell<C, 2>(logit, gl, gt_xywh + tcell * 4, gt_cls + tcell * C, cell, S, S2,
+                                    BX, C, cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf, acc_cls);
+            else
+                loss_obj_cell<C, 1>(logit, gl, gt_xywh + tcell * 4, gt_cls + tcell * C, cell, S, S2,
+                                    BX, C, cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf, acc_cls);
         }
     }
     loss_block_reduce(acc_coord, acc_conf, acc_cls, partials, bid);   // has a barrier after the LDS writes
