@@ -493,7 +493,23 @@ __device__ __forceinline__ void loss_block(
         if (item < nitems && img < batch) {
             const long long tcell = img * S2 + cell;
             has_obj = obj_mask[tcell] != 0;
-            if (!has_obj) {
+            if (has_obj) {
+                // the cell's logits are requested now and wait for pass 2 in the very tile
+                // slots their gradients will take (one memory round trip less on the
+                // path of the two wavefronts that do pass 2)
+                const float* p = pred + img * (long long)D * S2 + cell;
+                float v[D];
+#pragma unroll
+                for (int ch = 0; ch < D; ++ch) v[ch] = p[ch * S2];
+                if constexpr (BIAS) {
+                    const float* bq = bias + cell;
+#pragma unroll
+                    for (int ch = 0; ch < D; ++ch) v[ch] += bq[ch * S2];
+                }
+                float* gl = sgrad + pad + gi * (D * S2) + cell;
+#pragma unroll
+                for (int ch = 0; ch < D; ++ch) gl[ch * S2] = v[ch];
+            } else {
                 const float* p = pred + img * (long long)D * S2 + cell;
                 float vc[BX];
 #pragma unroll
@@ -533,17 +549,11 @@ __device__ __forceinline__ void loss_block(
             const int cell = item - gi * S2;
             const long long img = img0 + gi;
             const long long tcell = img * S2 + cell;
-            const float* p = pred + img * (long long)D * S2 + cell;
+            float* gl = sgrad + pad + gi * (D * S2) + cell;
             float v[D];
 #pragma unroll
-            for (int ch = 0; ch < D; ++ch) v[ch] = p[ch * S2];
-            if constexpr (BIAS) {
-                const float* bq = bias + cell;
-#pragma unroll
-                for (int ch = 0; ch < D; ++ch) v[ch] += bq[ch * S2];
-            }
+            for (int ch = 0; ch < D; ++ch) v[ch] = gl[ch * S2];
             auto logit = [&](int ch) -> float { return v[ch]; };
-            float* gl = sgrad + pad + gi * (D * S2) + cell;
             if (cls_role)
                 loss_obj_cell<C, 2>(logit, gl, gt_xywh + tcell * 4, gt_cls + tcell * C, cell, S, S2,
                                     BX, C, cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf, acc_cls);
