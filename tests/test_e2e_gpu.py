@@ -64,3 +64,17 @@ def test_grad_scaler_sequence(dev):
     scaler.step(optim)
     scaler.update()
     assert torch.isfinite(net[-1].bias).all()
+
+
+def test_half_precision_backbone_output(dev):
+    """A backbone run under autocast hands over fp16: get_loss computes in fp32 and
+    the gradient comes back in the backbone's dtype."""
+    from yolo_amd import YOLOv1Head, synth
+    head = YOLOv1Head()
+    pred, gx, gc, om = (x.to(dev) for x in synth.make_inputs(8, seed=12))
+    half = pred.half().requires_grad_(True)
+    loss = head.get_loss(half, gx, gc, om)
+    loss.backward()
+    want = head.get_loss(half.detach().float(), gx, gc, om)
+    assert loss.dtype == torch.float32 and abs(loss.item() - want.item()) <= 1e-6 * abs(want.item())
+    assert half.grad is not None and half.grad.dtype == torch.float16 and torch.isfinite(half.grad).all()

@@ -366,6 +366,8 @@ class YOLOv1Head(nn.Module):
         when this call sees one shard of a data-parallel batch (the shard losses
         then add up to the global loss)."""
         out = self(image)
+        if out.dtype in (torch.float16, torch.bfloat16):
+            out = out.float()      # a backbone run under autocast: the head computes in fp32
         gb = out.shape[0] if global_batch is None else int(global_batch)
         inv = 1.0 / max(gb, 1)
         if torch.is_grad_enabled() and out.requires_grad:
