@@ -95,3 +95,31 @@ def test_stress_shape_full_batch(dev):
     assert torch.equal(torch.cat([g0, g1]), grad)
     want = terms[:4].cpu().double()
     assert (((t0[:4] + t1[:4]).cpu().double() - want).abs() <= 1e-6 * want.abs()).all()
+
+
+def test_maximum_sizes(dev):
+    """The limits the header states: S = 64, Bx = 16, C = 4096 for the loss and the
+    grid decode; 1,024 candidates per image for the NMS entry points (S = 32 with one
+    predictor, and S = 8 with sixteen), beyond which they refuse."""
+    from yolo_amd import MODE_REFERENCE, _lib
+    import numpy as np
+    S, Bx, C = 64, 16, 4096
+    head = YOLOv1Head(img_size=64 * 8, n_cells=S, n_bboxes=Bx, n_classes=C)
+    pred, gx, gc, om = synth.make_inputs(1, S, Bx, C, 64 * 8, seed=5)
+    ref = ref_cpu.loss_and_grad(pred, gx, gc, om, n_cells=S, n_bboxes=Bx, n_classes=C, img_size=64 * 8)
+    terms, grad = head.loss_fwd_bwd(pred.to(dev), gx.to(dev), gc.to(dev), om.to(dev))
+    assert abs(terms[4].item() - ref["loss"].item()) <= 1e-5 * abs(ref["loss"].item())
+    assert (grad.cpu() - ref["grad"]).abs().max().item() <= 1e-5 * ref["grad"].abs().max().item()
+    ltrb = head.get_ltrb(pred.to(dev))
+    want = ref_cpu.get_ltrb(pred, S, Bx, 64 * 8)
+    torch.testing.assert_close(ltrb.cpu(), want, rtol=1e-5, atol=2e-4)
+    rc = _lib.load().yh_decode_nms(pred.to(dev).data_ptr(), 1, 1, None, 0, 0.5, 0.5, 1, S, Bx, C, 512, None)
+    assert rc == _lib.YH_ERR_UNSUPPORTED
+    for S, Bx, C, mode in ((32, 1, 4096, MODE_DENSE), (8, 16, 33, MODE_DENSE), (22, 2, 7, MODE_REFERENCE)):
+        head = YOLOv1Head(img_size=32 * S, n_cells=S, n_bboxes=Bx, n_classes=C)
+        pred = synth.make_pred(2, S, Bx, C, seed=S + Bx).to(dev)
+        got = head.postprocess(pred, 0.3, 0.5, mode, return_idx=True)
+        l, s, c, p = head.decode_candidates(pred, mode)
+        want = ref_cpu.nms_batch(l.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy(), p.cpu().numpy(), 0.3, 0.5)
+        for g_, w in zip(got, want):
+            np.testing.assert_array_equal(g_.cpu().numpy().view(np.uint32), np.asarray(w).view(np.uint32))
