@@ -6,6 +6,8 @@ bit).  The shapes are drawn so that every launch variant is hit: one wavefront
 per image with one or two candidates per lane, one workgroup per image with
 1, 2 or 4 candidates per thread, class counts that are and are not multiples
 of four, more cells than threads in a workgroup."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -19,7 +21,7 @@ pytestmark = pytest.mark.gpu
 def configs():
     rng = np.random.default_rng(20240607)
     out = []
-    while len(out) < 64:
+    while len(out) < int(os.environ.get("YH_SWEEP_CONFIGS", "64")):
         S = int(rng.integers(1, 15))
         Bx = int(rng.integers(1, 6))
         C = int(rng.choice([1, 2, 3, 4, 7, 20, 21, 33, 80, 100]))
