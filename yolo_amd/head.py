@@ -32,6 +32,26 @@ def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+class _on_device:
+    """``torch.cuda.device(dev)`` only when ``dev`` is not already current (the
+    context manager costs several microseconds per call otherwise)."""
+
+    __slots__ = ("ctx",)
+
+    def __init__(self, device):
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        self.ctx = None if idx == torch.cuda.current_device() else torch.cuda.device(idx)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 def _need(t: torch.Tensor, name: str, dtype, shape=None) -> torch.Tensor:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
@@ -89,7 +109,7 @@ class _LossFunction(torch.autograd.Function):
         go = grad_output
         if go.dtype != torch.float32 or go.numel() != 1 or go.device != grad.device:
             go = go.to(device=grad.device, dtype=torch.float32).reshape(())
-        with torch.cuda.device(grad.device):
+        with _on_device(grad.device):
             _lib.check(_lib.load().yh_scale_grad(grad.data_ptr(), go.data_ptr(), grad.numel(),
                                                  _stream(grad.device)))
         return grad, None, None, None, None, None
@@ -120,7 +140,7 @@ class _LinearLossFunction(torch.autograd.Function):
         if go.dtype != torch.float32 or go.numel() != 1 or go.device != grad.device:
             go = go.to(device=grad.device, dtype=torch.float32).reshape(())
         lib = _lib.load()
-        with torch.cuda.device(grad.device):
+        with _on_device(grad.device):
             _lib.check(lib.yh_scale_grad(grad.data_ptr(), go.data_ptr(), grad.numel(),
                                          _stream(grad.device)))
             if grad_bias is not None:
@@ -215,8 +235,15 @@ class YOLOv1Head(nn.Module):
         terms = torch.empty(5, dtype=torch.float32, device=out.device)
         if log is not None and log.ring.device != out.device:
             raise ValueError(f"loss log on {log.ring.device}, out is on {out.device}")
-        with torch.cuda.device(out.device):
+        with _on_device(out.device):
             st = _stream(out.device)
+            if log is None and finalize_stream is None:
+                _lib.check(lib.yh_loss_fwd_bwd(
+                    out.data_ptr(), gt_norm_xywh.data_ptr(), gt_cls_prob.data_ptr(),
+                    obj_mask.data_ptr(), grad.data_ptr(), terms.data_ptr(), ws.data_ptr(),
+                    ws.numel(), bsz, self.n_cells, self.n_bboxes, self.n_classes, self.img_size,
+                    self.coord_coeff, self.noobj_coeff, float(inv_global_batch), st))
+                return terms, grad
             _lib.check(lib.yh_loss_partials(
                 out.data_ptr(), gt_norm_xywh.data_ptr(), gt_cls_prob.data_ptr(),
                 obj_mask.data_ptr(), grad.data_ptr(), ws.data_ptr(), ws.numel(), bsz,
@@ -272,7 +299,7 @@ class YOLOv1Head(nn.Module):
             self._pipe[out.device] = state
         ws, phase = state[0], 1 - state[1]
         grad = torch.empty_like(out)
-        with torch.cuda.device(out.device):
+        with _on_device(out.device):
             _lib.check(lib.yh_loss_fwd_bwd_pipelined(
                 out.data_ptr(), gt_norm_xywh.data_ptr(), gt_cls_prob.data_ptr(),
                 obj_mask.data_ptr(), grad.data_ptr(), _ptr(terms_prev), log.ring.data_ptr(),
@@ -287,7 +314,7 @@ class YOLOv1Head(nn.Module):
         state = self._pipe.get(log.ring.device)
         if state is None:
             return
-        with torch.cuda.device(log.ring.device):
+        with _on_device(log.ring.device):
             _lib.check(_lib.load().yh_loss_pipelined_flush(
                 state[0].data_ptr(), state[0].numel(), state[1], _ptr(terms), log.ring.data_ptr(),
                 log.capacity, log.cursor.data_ptr(), _stream(log.ring.device)))
@@ -335,7 +362,7 @@ class YOLOv1Head(nn.Module):
         grad = torch.empty_like(z)
         terms = torch.empty(5, dtype=torch.float32, device=out.device)
         grad_bias = None
-        with torch.cuda.device(out.device):
+        with _on_device(out.device):
             st = _stream(out.device)
             _lib.check(lib.yh_loss_fwd_bwd_linear(
                 out.data_ptr(), bias.data_ptr(), gt_norm_xywh.data_ptr(), gt_cls_prob.data_ptr(),
@@ -396,7 +423,7 @@ class YOLOv1Head(nn.Module):
         gx = torch.empty(bsz, n, 1, 4, dtype=torch.float32, device=dev)
         gc = torch.empty(bsz, n, 1, self.n_classes, dtype=torch.float32, device=dev)
         om = torch.empty(bsz, n, 1, 1, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _lib.check(_lib.load().yh_encode_targets(
                 gt_ltrb.data_ptr(), gt_label.data_ptr(), gt_count.data_ptr(), gx.data_ptr(),
                 gc.data_ptr(), om.data_ptr(), bsz, m, self.n_cells, self.n_classes,
@@ -422,7 +449,7 @@ class YOLOv1Head(nn.Module):
             res["best_ltrb"] = torch.empty(bsz, n, 1, 4, dtype=torch.float32, device=dev)
         if "conf_mask" in want:
             res["conf_mask"] = torch.empty(bsz, n, 1, 1, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _lib.check(_lib.load().yh_decode_grid(
                 out.data_ptr(), _ptr(res.get("ltrb")), _ptr(res.get("conf")),
                 _ptr(res.get("cls_prob")), _ptr(res.get("cls_idx")), _ptr(res.get("best_k")),
@@ -440,7 +467,7 @@ class YOLOv1Head(nn.Module):
         out = self._check_out(out.detach())
         res = torch.empty(out.shape[0], self.n_grid, self.n_bboxes, 4, dtype=torch.float32,
                           device=out.device)
-        with torch.cuda.device(out.device):
+        with _on_device(out.device):
             _lib.check(_lib.load().yh_norm_xywh(out.data_ptr(), res.data_ptr(), out.shape[0],
                                                 self.n_cells, self.n_bboxes, self.n_classes,
                                                 _stream(out.device)))
@@ -455,7 +482,7 @@ class YOLOv1Head(nn.Module):
             raise ValueError(f"norm_xywh: expected (B, {self.n_grid}, K, 4), got {tuple(shape)}")
         bsz = shape[0] if norm_xywh.dim() == 4 else 1
         res = torch.empty_like(norm_xywh)
-        with torch.cuda.device(norm_xywh.device):
+        with _on_device(norm_xywh.device):
             _lib.check(_lib.load().yh_denormalize_xywh(
                 norm_xywh.data_ptr(), res.data_ptr(), bsz, self.n_cells, shape[-2], self.img_size,
                 _stream(norm_xywh.device)))
@@ -467,7 +494,7 @@ class YOLOv1Head(nn.Module):
         if xywh.shape[-1] != 4:
             raise ValueError(f"xywh: expected (..., 4), got {tuple(xywh.shape)}")
         res = torch.empty_like(xywh)
-        with torch.cuda.device(xywh.device):
+        with _on_device(xywh.device):
             _lib.check(_lib.load().yh_xywh_to_ltrb(xywh.data_ptr(), res.data_ptr(),
                                                    xywh.numel() // 4, self.img_size,
                                                    _stream(xywh.device)))
@@ -484,7 +511,7 @@ class YOLOv1Head(nn.Module):
             obj_mask = obj_mask.view(torch.uint8)
         _need(obj_mask, "obj_mask", torch.uint8, (bsz, n, 1, 1))
         res = torch.empty(bsz, n, self.n_bboxes, 1, dtype=torch.uint8, device=out.device)
-        with torch.cuda.device(out.device):
+        with _on_device(out.device):
             _lib.check(_lib.load().yh_responsibility_mask(
                 out.data_ptr(), gt_norm_xywh.data_ptr(), obj_mask.data_ptr(), res.data_ptr(), bsz,
                 self.n_cells, self.n_bboxes, self.n_classes, self.img_size, _stream(out.device)))
@@ -551,7 +578,7 @@ class YOLOv1Head(nn.Module):
         score = torch.empty(bsz, nn_, dtype=torch.float32, device=dev)
         cls = torch.empty(bsz, nn_, dtype=torch.int32, device=dev)
         present = torch.empty(bsz, nn_, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _lib.check(_lib.load().yh_decode_candidates(
                 out.data_ptr(), ltrb.data_ptr(), score.data_ptr(), cls.data_ptr(),
                 present.data_ptr(), int(mode), bsz, self.n_cells, self.n_bboxes, self.n_classes,
@@ -578,7 +605,7 @@ class YOLOv1Head(nn.Module):
         tail = (dets.data_ptr(), count.data_ptr(), _ptr(kidx), int(mode), float(conf_thresh),
                 float(iou_thresh), bsz, self.n_cells, self.n_bboxes, self.n_classes, self.img_size,
                 _stream(dev))
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             if bias is None:
                 _lib.check(_lib.load().yh_decode_nms(out.data_ptr(), *tail))
             else:
@@ -603,7 +630,7 @@ class YOLOv1Head(nn.Module):
         dets = torch.empty(bsz, n, 6, dtype=torch.float32, device=dev)
         count = torch.empty(bsz, dtype=torch.int32, device=dev)
         kidx = torch.empty(bsz, n, dtype=torch.int32, device=dev) if return_idx else None
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _lib.check(_lib.load().yh_nms(
                 ltrb.data_ptr(), score.data_ptr(), cls.data_ptr(), _ptr(present),
                 dets.data_ptr(), count.data_ptr(), _ptr(kidx), float(conf_thresh),
