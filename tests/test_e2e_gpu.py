@@ -78,3 +78,17 @@ def test_half_precision_backbone_output(dev):
     want = head.get_loss(half.detach().float(), gx, gc, om)
     assert loss.dtype == torch.float32 and abs(loss.item() - want.item()) <= 1e-6 * abs(want.item())
     assert half.grad is not None and half.grad.dtype == torch.float16 and torch.isfinite(half.grad).all()
+
+
+def test_validation_under_inference_mode(dev):
+    """train.py:100-110: validate() calls get_loss under torch.inference_mode()."""
+    from yolo_amd import YOLOv1Head, synth
+    head = YOLOv1Head()
+    pred, gx, gc, om = (x.to(dev) for x in synth.make_inputs(8, seed=13))
+    want = head.get_loss(pred, gx, gc, om).item()
+    with torch.inference_mode():
+        p2 = pred.clone()
+        loss = head.get_loss(p2, gx, gc, om)
+        dets, count = head.postprocess(p2, 0.5, 0.5)
+    assert loss.item() == want and not loss.requires_grad
+    assert int(count.sum()) > 0 and dets.shape == (8, 98, 6)
