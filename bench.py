@@ -216,15 +216,35 @@ def main():
     graphs = {}
     if use_graph:
         try:
+            # graphs of spg steps, of every smaller power of two (a remainder then takes a
+            # few launches, not one per step) and, last, of a single step
+            sizes = sorted({spg} | {1 << b for b in range(1, 16) if (1 << b) < spg}, reverse=True)
+
+            def capture(fn, st, n):
+                g = torch.cuda.CUDAGraph()
+                # thread_local: the process group's watchdog thread may touch the HIP
+                # runtime while this thread captures
+                with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+                    for _ in range(n):
+                        fn()
+                return g
+
             for name, fn, st in (("loss", loss_step, s_loss), ("nms", nms_step, s_nms)):
-                for n in sorted({2 if pipelined else 1, spg}):
-                    g = torch.cuda.CUDAGraph()
-                    # thread_local: the process group's watchdog thread may touch the HIP
-                    # runtime while this thread captures
-                    with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
-                        for _ in range(n):
-                            fn()
-                    graphs[(name, n)] = g
+                for n in sizes:
+                    graphs[(name, n)] = capture(fn, st, n)
+            graphs[("nms", 1)] = capture(nms_step, s_nms, 1)
+
+            def odd_loss_step():
+                # A single pipelined step between two flushes: whatever half the step
+                # before it used, nothing is pending when it starts or ends.  Captured
+                # last, because it leaves the head's phase count flipped.
+                if pipelined:
+                    head.flush_loss_log(log)
+                loss_step()
+                if pipelined:
+                    head.flush_loss_log(log)
+
+            graphs[("loss", 1)] = capture(odd_loss_step, s_loss, 1)
         except Exception as exc:  # capture unsupported: fall back to eager launches
             if rank == 0:
                 print(f"[bench] graph capture failed ({exc!r}); running eagerly", file=sys.stderr)
@@ -240,19 +260,14 @@ def main():
                     graphs[("loss", spg)].replay()
                 with torch.cuda.stream(s_nms):
                     graphs[("nms", spg)].replay()
-            rest, unit = n % spg, 2 if pipelined else 1
-            for _ in range(rest // unit):
-                with torch.cuda.stream(s_loss):
-                    graphs[("loss", unit)].replay()
-                with torch.cuda.stream(s_nms):
-                    graphs[("nms", unit)].replay()
-            if rest % unit:                          # one odd step: eagerly, between two flushes --
-                loss_flush()                         # the replays moved on without the head's phase count
-                with torch.cuda.stream(s_loss):
-                    loss_step()
-                with torch.cuda.stream(s_nms):
-                    nms_step()
-                loss_flush()
+            rest = n % spg
+            for size in sizes[1:] + [1]:
+                while rest >= size:
+                    with torch.cuda.stream(s_loss):
+                        graphs[("loss", size)].replay()
+                    with torch.cuda.stream(s_nms):
+                        graphs[("nms", size)].replay()
+                    rest -= size
         else:
             for _ in range(n):
                 with torch.cuda.stream(s_loss):
