@@ -1,4 +1,8 @@
-"""Host-side target encoding for the YOLOv1 head.
+"""Host-side target encoding for the YOLOv1 head: the data loader's collate step,
+where the boxes still live in host memory (data.py:196-209).  It is not a
+fallback for anything on the GPU path -- on the device the same encoding is
+``YOLOv1Head.encode_targets`` (yh_encode_targets), and no GPU entry point calls
+into this module.
 
 Turns per-image ground-truth boxes (pixel ltrb) and labels into the three
 tensors the head's loss consumes:
