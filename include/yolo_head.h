@@ -48,7 +48,7 @@ extern "C" {
 #define YH_MAX_S 64
 #define YH_MAX_BX 16
 #define YH_MAX_C 4096
-#define YH_MAX_CANDIDATES 1024 /* per image, for the NMS entry points */
+#define YH_MAX_CANDIDATES 2048 /* per image, for the NMS entry points */
 
 /* op codes for yh_workspace_bytes */
 #define YH_OP_LOSS 0

@@ -99,8 +99,8 @@ def test_stress_shape_full_batch(dev):
 
 def test_maximum_sizes(dev):
     """The limits the header states: S = 64, Bx = 16, C = 4096 for the loss and the
-    grid decode; 1,024 candidates per image for the NMS entry points (S = 32 with one
-    predictor, and S = 8 with sixteen), beyond which they refuse."""
+    grid decode; S*S*Bx = 2,048 rows per image for the NMS entry points (S = 32 with two
+    predictors, S = 45 with one), beyond which they refuse."""
     from yolo_amd import MODE_REFERENCE, _lib
     import numpy as np
     S, Bx, C = 64, 16, 4096
@@ -115,7 +115,8 @@ def test_maximum_sizes(dev):
     torch.testing.assert_close(ltrb.cpu(), want, rtol=1e-5, atol=2e-4)
     rc = _lib.load().yh_decode_nms(pred.to(dev).data_ptr(), 1, 1, None, 0, 0.5, 0.5, 1, S, Bx, C, 512, None)
     assert rc == _lib.YH_ERR_UNSUPPORTED
-    for S, Bx, C, mode in ((32, 1, 4096, MODE_DENSE), (8, 16, 33, MODE_DENSE), (22, 2, 7, MODE_REFERENCE)):
+    for S, Bx, C, mode in ((32, 1, 4096, MODE_DENSE), (8, 16, 33, MODE_DENSE), (22, 2, 7, MODE_REFERENCE),
+                           (32, 2, 4096, MODE_DENSE), (32, 2, 7, MODE_REFERENCE), (45, 1, 11, MODE_DENSE)):
         head = YOLOv1Head(img_size=32 * S, n_cells=S, n_bboxes=Bx, n_classes=C)
         pred = synth.make_pred(2, S, Bx, C, seed=S + Bx).to(dev)
         got = head.postprocess(pred, 0.3, 0.5, mode, return_idx=True)

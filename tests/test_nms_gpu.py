@@ -67,7 +67,10 @@ def test_decode_candidates_match_oracle(dev, mode):
     (3, 200, 5, 0.2, 0.5),      # one workgroup per image
     (3, 500, 80, 0.001, 0.5),
     (2, 980, 80, 0.001, 0.5),   # the stress shape S=14, B=5, C=80
-    (2, 1024, 1, 0.0, 0.6),     # maximum size, one class
+    (2, 1024, 1, 0.0, 0.6),     # one class: the step loop over a 1,024-member segment
+    (2, 1500, 40, 0.001, 0.5),  # eight candidates per thread
+    (2, 2048, 300, 0.0, 0.5),   # maximum size, short segments (pair path)
+    (1, 2048, 3, 0.0, 0.4),     # maximum size, segments longer than 64 (step loop)
 ])
 def test_nms_bit_exact(dev, batch, n, ncls, ct, it):
     ltrb, score, cls, present = random_candidates(batch, n, ncls, seed=n + batch)
@@ -113,6 +116,8 @@ def test_nms_tie_and_degenerate_cases(dev):
     (14, 5, 80, 4, MODE_REFERENCE, 0.3, 0.5),
     (3, 1, 4, 9, MODE_REFERENCE, 0.2, 0.5),
     (11, 3, 7, 5, MODE_DENSE, 0.4, 0.45),
+    (20, 5, 80, 2, MODE_DENSE, 0.001, 0.5),      # 2,000 candidates per image
+    (40, 1, 6, 2, MODE_REFERENCE, 0.3, 0.5),     # 1,600 cells
 ])
 def test_fused_decode_nms(dev, S, Bx, C, batch, mode, ct, it):
     img = 32 * S

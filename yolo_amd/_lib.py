@@ -35,7 +35,7 @@ YH_OP_LOSS_PIPELINED = 5
 YH_MODE_REFERENCE = 0
 YH_MODE_DENSE = 1
 
-YH_MAX_CANDIDATES = 1024
+YH_MAX_CANDIDATES = 2048
 
 YH_BOX_IOU = 0
 YH_BOX_GIOU = 1

@@ -72,7 +72,7 @@ void nms_layout(yh::NmsArgs& a, int slot_pad) {
     a.off_segst = off;
     off += round16(a.nc * 4);
     a.off_pair = off;     // pair offsets per position + per-chunk totals (a workgroup per image)
-    off += slot_pad > 128 ? round16((slot_pad + 1 + 16) * 4) : 0;
+    off += slot_pad > 128 ? round16((slot_pad + 1 + slot_pad / 64) * 4) : 0;
     a.region_bytes = off;
 }
 
@@ -96,11 +96,19 @@ int launch_nms_shape(yh::NmsArgs a, hipStream_t st) {
                            dim3(yh::NMS_BLOCK), lds, st, a);                                \
         return launch_status();                                                             \
     }
-    if (a.nslot <= 64) YH_NMS_CASE(64, 1)
-    if (a.nslot <= 128) YH_NMS_CASE(64, 2)
-    if (a.nslot <= 256) YH_NMS_CASE(256, 1)
-    if (a.nslot <= 512) YH_NMS_CASE(256, 2)
-    YH_NMS_CASE(256, 4)
+    // a compile-time shape has two possible slot counts (S*S and S*S*Bx): only the
+    // cases those need are instantiated
+    constexpr int kCells = S_CT * S_CT, kBoxes = S_CT * S_CT * BX_CT;
+#define YH_NMS_FITS(LO, HI) \
+    (S_CT == 0 || (kCells > LO && kCells <= HI) || (kBoxes > LO && kBoxes <= HI))
+    if constexpr (YH_NMS_FITS(0, 64)) if (a.nslot <= 64) YH_NMS_CASE(64, 1)
+    if constexpr (YH_NMS_FITS(64, 128)) if (a.nslot <= 128) YH_NMS_CASE(64, 2)
+    if constexpr (YH_NMS_FITS(128, 256)) if (a.nslot <= 256) YH_NMS_CASE(256, 1)
+    if constexpr (YH_NMS_FITS(256, 512)) if (a.nslot <= 512) YH_NMS_CASE(256, 2)
+    if constexpr (YH_NMS_FITS(512, 1024)) if (a.nslot <= 1024) YH_NMS_CASE(256, 4)
+    if constexpr (YH_NMS_FITS(1024, 2048)) if (a.nslot <= 2048) YH_NMS_CASE(256, 8)
+    return YH_ERR_UNSUPPORTED;
+#undef YH_NMS_FITS
 #undef YH_NMS_CASE
 }
 
@@ -135,7 +143,7 @@ const char* yh_strerror(int rc) {
         case YH_ERR_WORKSPACE: return "yolo_head: workspace missing or too small";
         case YH_ERR_ALIGN: return "yolo_head: pointer not aligned as documented";
         case YH_ERR_ARG: return "yolo_head: invalid scalar argument";
-        case YH_ERR_UNSUPPORTED: return "yolo_head: more than 1024 candidates per image";
+        case YH_ERR_UNSUPPORTED: return "yolo_head: more than 2048 candidates per image";
         default: break;
     }
     if (rc > 0) return hipGetErrorString((hipError_t)rc);
