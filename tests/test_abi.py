@@ -93,8 +93,8 @@ def test_nms_argument_errors():
     assert lib.yh_decode_nms(f, f, f, None, 0, float("nan"), 0.5, 4, 7, 2, 20, 448, None) == _lib.YH_ERR_ARG
     assert lib.yh_decode_nms(None, f, f, None, 0, 0.5, 0.5, 4, 7, 2, 20, 448, None) == _lib.YH_ERR_NULL
     # 32*32*2 = 2048 candidates per image
-    assert lib.yh_decode_nms(f, f, f, None, 1, 0.5, 0.5, 4, 32, 2, 20, 448, None) == _lib.YH_ERR_UNSUPPORTED
-    assert lib.yh_nms(f, f, f, None, f, f, None, 0.5, 0.5, 4, 2000, None) == _lib.YH_ERR_UNSUPPORTED
+    assert lib.yh_decode_nms(f, f, f, None, 1, 0.5, 0.5, 4, 32, 3, 20, 448, None) == _lib.YH_ERR_UNSUPPORTED
+    assert lib.yh_nms(f, f, f, None, f, f, None, 0.5, 0.5, 4, 2049, None) == _lib.YH_ERR_UNSUPPORTED
     assert lib.yh_nms(f, f, f, None, f, f, None, 0.5, 0.5, 4, 0, None) == _lib.YH_ERR_SHAPE
     assert lib.yh_nms(f + 4, f, f, None, f, f, None, 0.5, 0.5, 4, 10, None) == _lib.YH_ERR_ALIGN
     # batch 0 is a valid no-op everywhere
