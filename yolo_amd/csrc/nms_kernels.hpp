@@ -43,8 +43,9 @@ struct NmsArgs {
     int nslot;  // candidate slots per image (S*S in reference mode, S*S*nb dense, N for source 1)
     int nout;   // rows of dets per image
     float cellf, imgf, conf_thr, iou_thr;
+    IouGate gate;   // iou_thr, prepared for the division-free comparison
     // per-image LDS region: byte offsets of the arrays inside it, and its size
-    int off_keys, off_box, off_meta, off_alive, off_misc, off_ccls, off_hist, off_segst, off_pair;
+    int off_keys, off_box, off_meta, off_seg, off_alive, off_misc, off_ccls, off_hist, off_segst, off_pair;
     int region_bytes;
     int dbg_stop;  // builds with -DYH_PHASE_PROBE only: leave after this phase (0 = run everything)
 };
@@ -163,7 +164,10 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
     unsigned char* region = smem + (size_t)sub * a.region_bytes;
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(region + a.off_keys);
     float4* sbox = reinterpret_cast<float4*>(region + a.off_box);
-    int4* smeta = reinterpret_cast<int4*>(region + a.off_meta);
+    // per sorted position: {score bits, class << 16 | flat index}, and the first
+    // position of its class segment
+    int2* smeta = reinterpret_cast<int2*>(region + a.off_meta);
+    int* sseg = reinterpret_cast<int*>(region + a.off_seg);
     unsigned long long* alive = reinterpret_cast<unsigned long long*>(region + a.off_alive);
     int* misc = reinterpret_cast<int*>(region + a.off_misc);  // [0] valid count, [1] max pos, [4..7] scan carries
     int* ccls = reinterpret_cast<int*>(region + a.off_ccls);
@@ -404,7 +408,8 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
     for (int e = 0; e < ITEMS; ++e) {
         if (cvalid[e]) {
             sbox[rank[e]] = make_float4(cbox[e].l, cbox[e].t, cbox[e].r, cbox[e].b);
-            smeta[rank[e]] = make_int4(__float_as_int(cscore[e]), ccl[e], cidx[e], seg[e]);
+            smeta[rank[e]] = make_int2(__float_as_int(cscore[e]), (ccl[e] << 16) | cidx[e]);
+            if constexpr (!kWave) sseg[rank[e]] = seg[e];   // kWave: found from the sorted order below
             mp_local = max(mp_local, rank[e] - seg[e]);
         }
         if constexpr (!kWave) nv_local += __popcll(__ballot(cvalid[e]));
@@ -436,7 +441,8 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         if (al[e]) {
             const float4 b = sbox[i];
             mybox[e] = {b.x, b.y, b.z, b.w};
-            mymeta[e] = smeta[i];
+            const int2 m = smeta[i];
+            mymeta[e] = make_int4(m.x, m.y >> 16, m.y & 0xffff, kWave ? 0 : sseg[i]);
         }
     }
     if constexpr (kWave) {
@@ -505,8 +511,13 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         // the members in its word.  No barrier per member, and every lane of the
         // pair loop has work.
         unsigned long long* kills = keys;     // the keys are not needed any more
-        int* poff = reinterpret_cast<int*>(region + a.off_pair);   // pairs before position p
-        int* ctot = poff + NT * ITEMS + 1;                           // pairs per chunk of 64
+        // pairs before position p; the array takes the place of smeta, which every
+        // thread has read into registers before the barrier below
+        int* poff = reinterpret_cast<int*>(region + a.off_pair);
+        int* slen = poff + NT * ITEMS;        // at a segment's first position: its member count
+        // pairs per chunk of 64, in the liveness words (not written before the greedy pass):
+        // this array is filled before the barrier, so it must not overlap smeta
+        int* ctot = reinterpret_cast<int*>(alive);
         int r[ITEMS], excl[ITEMS];
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
@@ -534,7 +545,12 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                 if (q < e * NW + wv) carry += v;
                 npairs += e == 0 ? v : 0;
             }
-            if (al[e]) poff[e * NT + t] = carry + excl[e];
+            if (al[e]) {
+                const int i = e * NT + t;
+                poff[i] = carry + excl[e];
+                const int nxt = i + 1 < nvalid ? sseg[i + 1] : -1;
+                if (nxt != mymeta[e].w) slen[mymeta[e].w] = r[e] + 1;   // the segment's last member
+            }
         }
         group_sync<NT>();
 #ifdef YH_PHASE_PROBE
@@ -550,49 +566,58 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                 const int mid = (lo + hi + 1) >> 1;
                 if (poff[mid] <= k) lo = mid; else hi = mid - 1;
             }
-            int p = lo;
-            int4 mp = smeta[p];
+            // Pairs are numbered by later member, then by earlier member, so inside a
+            // segment of L members the walk is register arithmetic: (ii, j) -> (ii + 1, j)
+            // -> ... -> (0, j + 1); the next segment starts at sp + L, and its length is
+            // fetched one segment ahead.  The loop is bound by instruction issue (the
+            // other wavefronts of the SIMD cover the LDS latency), so it is written for
+            // instruction count: no prefetch registers, no division.
+            const int p = lo;
+            int sp = sseg[p];                     // first position of the segment
+            int L = slen[sp];
+            int j = p - sp;                       // later member, as an index into the segment
+            int ii = k - poff[p];                 // earlier member, ii < j
+            int nL = sp + L < nvalid ? slen[sp + L] : 0;
             float4 bp = sbox[p];
-            int ii = k - poff[p];                 // index of the earlier member in the segment
-            float4 b = sbox[mp.w + ii];
+            const IouGate gate = a.gate;
             for (; k < kend; ++k) {
-                // state of the next pair first, so that its box is in flight during the IoU
-                const int cur_i = mp.w + ii, cur_bit = p - mp.w;
-                const float4 cb = b, cbp = bp;
-                if (k + 1 < kend) {
-                    if (++ii == p - mp.w) {
-                        do { ++p; mp = smeta[p]; } while (p == mp.w);   // segment heads own no pair
-                        bp = sbox[p];
-                        ii = 0;
+                const float4 b = sbox[sp + ii];
+                if (iou_above({b.x, b.y, b.z, b.w}, {bp.x, bp.y, bp.z, bp.w}, gate))
+                    atomicOr(&kills[sp + ii], 1ull << j);
+                if (++ii == j) {
+                    ii = 0;
+                    if (++j == L) {
+                        if (k + 1 >= kend) break;
+                        // a later pair exists, so a later segment has two members or more;
+                        // one-member segments are stepped over
+                        do {
+                            sp += L;
+                            L = nL;
+                            nL = sp + L < nvalid ? slen[sp + L] : 0;
+                        } while (L == 1);
+                        j = 1;
                     }
-                    b = sbox[mp.w + ii];
+                    bp = sbox[sp + j];
                 }
-                if (iou_pair({cb.x, cb.y, cb.z, cb.w}, {cbp.x, cbp.y, cbp.z, cbp.w}) > a.iou_thr)
-                    atomicOr(&kills[cur_i], 1ull << cur_bit);
             }
         }
         group_sync<NT>();
 #ifdef YH_PHASE_PROBE
         if (a.dbg_stop == 6) return;
 #endif
-        // segment lengths, left at the head's slot of the (now free) offset array;
-        // the heads queue up in a list (any order: segments are independent)
+        // the segment heads queue up in a list (any order: segments are independent)
         int* hlist = reinterpret_cast<int*>(sbox);   // every box is in registers by now
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
             const int i = e * NT + t;
-            if (al[e]) {
-                const int nxt = i + 1 < nvalid ? smeta[i + 1].w : -1;
-                if (nxt != mymeta[e].w) poff[mymeta[e].w] = r[e] + 1;
-                if (r[e] == 0) hlist[atomicAdd(&misc[2], 1)] = i;
-            }
+            if (al[e] && r[e] == 0) hlist[atomicAdd(&misc[2], 1)] = i;
         }
         group_sync<NT>();
         // one lane per segment: greedy pass over its members, eight words per round trip
         const int nheads = misc[2];
         for (int h = t; h < nheads; h += NT) {
             const int head = hlist[h];
-            const int len = poff[head];
+            const int len = slen[head];
             unsigned long long dead = 0ull;
             for (int base = 0; base < len; base += 8) {
                 unsigned long long kw[8];

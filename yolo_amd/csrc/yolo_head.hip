@@ -60,7 +60,8 @@ void nms_layout(yh::NmsArgs& a, int slot_pad) {
     a.off_keys = 0;
     a.off_box = slot_pad * 8;
     a.off_meta = slot_pad * 24;
-    int off = slot_pad * (8 + 16 + 16);
+    a.off_seg = slot_pad * 32;
+    int off = slot_pad * (8 + 16 + 8 + 4);
     a.off_alive = off;
     off += round16((slot_pad / 64) * 8);
     a.off_misc = off;
@@ -71,8 +72,9 @@ void nms_layout(yh::NmsArgs& a, int slot_pad) {
     off += round16(a.nc * 4);
     a.off_segst = off;
     off += round16(a.nc * 4);
-    a.off_pair = off;     // pair offsets per position + per-chunk totals (a workgroup per image)
-    off += slot_pad > 128 ? round16((slot_pad + 1 + slot_pad / 64) * 4) : 0;
+    // pair offsets per position (a workgroup per image): slot_pad + 1 ints in the place of
+    // the 2 * slot_pad ints at off_meta, which are dead by then
+    a.off_pair = a.off_meta;
     a.region_bytes = off;
 }
 
@@ -596,6 +598,7 @@ int decode_nms_launch(const float* pred, const float* bias, float* dets, int32_t
     a.imgf = (float)img_size;
     a.conf_thr = conf_thresh;
     a.iou_thr = iou_thresh;
+    a.gate = yh::make_iou_gate(iou_thresh);
 #ifdef YH_PHASE_PROBE
     { const char* e = getenv("YH_NMS_STOP"); a.dbg_stop = e ? atoi(e) : 0; }
 #endif
@@ -645,6 +648,7 @@ int yh_nms(const float* cand_ltrb, const float* cand_score, const int32_t* cand_
     a.nout = N;
     a.conf_thr = conf_thresh;
     a.iou_thr = iou_thresh;
+    a.gate = yh::make_iou_gate(iou_thresh);
     return launch_nms<1>(a, (hipStream_t)stream);
 }
 
