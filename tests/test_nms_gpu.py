@@ -79,6 +79,40 @@ def test_nms_bit_exact(dev, batch, n, ncls, ct, it):
     assert_same(got, oracle_nms(ltrb, score, cls, present, ct, it))
 
 
+def test_iou_threshold_on_and_next_to_a_pair_iou(dev):
+    """The workgroup-per-image kernel decides IoU > threshold without dividing;
+    thresholds that ARE the IoU of some pair, and the floats next to it on either
+    side (odd and even last bits, so both tie directions), must give the oracle's
+    keep sets bit for bit.  Also thresholds outside [0, 1e30), which divide."""
+    ltrb, score, cls, present = random_candidates(2, 300, 30, seed=77)
+    b = ltrb[0].numpy()
+    c = cls[0].numpy()
+    thresholds = []
+    for i in range(300):
+        for j in range(i + 1, 300):
+            if c[i] != c[j]:
+                continue
+            iw = max(np.float32(min(b[i, 2], b[j, 2]) - max(b[i, 0], b[j, 0])), np.float32(0))
+            ih = max(np.float32(min(b[i, 3], b[j, 3]) - max(b[i, 1], b[j, 1])), np.float32(0))
+            inter = np.float32(iw * ih)
+            a1 = np.float32(max(b[i, 2] - b[i, 0], 0)) * np.float32(max(b[i, 3] - b[i, 1], 0))
+            a2 = np.float32(max(b[j, 2] - b[j, 0], 0)) * np.float32(max(b[j, 3] - b[j, 1], 0))
+            uni = np.float32(np.float32(a1 + a2) - inter)
+            if inter > 0 and uni > 0:
+                thresholds.append(np.float32(inter / uni))
+        if len(thresholds) >= 12:
+            break
+    assert len(thresholds) >= 12
+    cases = []
+    for v in thresholds[:12]:
+        cases += [float(np.nextafter(v, np.float32(-1))), float(v), float(np.nextafter(v, np.float32(2)))]
+    cases += [0.0, -0.25, 2e30, float("inf"), float(np.float32(1e-45))]
+    for it in cases:
+        got = YOLOv1Head.nms(ltrb.to(dev), score.to(dev), cls.to(dev), present.to(dev), 0.0, it,
+                             return_idx=True)
+        assert_same(got, oracle_nms(ltrb, score, cls, present, 0.0, it))
+
+
 def test_nms_tie_and_degenerate_cases(dev):
     f = torch.tensor
     ltrb = f([[[0, 0, 10, 10], [0, 0, 10, 20], [0, 0, 10, 10], [5, 5, 5, 5], [30, 30, 20, 20],
