@@ -207,6 +207,9 @@ class YOLOv1Head(nn.Module):
         return bias
 
     def _get_workspace(self, device, nbytes: int) -> torch.Tensor:
+        # One scratch buffer per device, reused by every loss call of this head: calls
+        # are ordered by the stream they are enqueued on, so a head serves one stream
+        # per device at a time (use one head per stream otherwise).
         ws = self._workspace.get(device)
         if ws is None or ws.numel() < nbytes:
             ws = torch.empty(max(nbytes, 4096), dtype=torch.uint8, device=device)
@@ -352,6 +355,10 @@ class YOLOv1Head(nn.Module):
         if obj_mask.dtype == torch.bool:
             obj_mask = obj_mask.view(torch.uint8)
         _need(obj_mask, "obj_mask", torch.uint8, (bsz, n, 1, 1))
+        for name, t in (("gt_norm_xywh", gt_norm_xywh), ("gt_cls_prob", gt_cls_prob),
+                        ("obj_mask", obj_mask)):
+            if t.device != out.device:
+                raise ValueError(f"{name}: on {t.device}, z is on {out.device}")
         lib = _lib.load()
         gb = bsz if global_batch is None else int(global_batch)
         shape = (bsz, self.n_cells, self.n_bboxes, self.n_classes)
