@@ -7,6 +7,8 @@
 // tiny kernel adds the rows in a fixed order, so results are reproducible bit
 // for bit.
 #pragma once
+#include <type_traits>
+
 #include "head_math.hpp"
 
 namespace yh {
@@ -74,10 +76,11 @@ __device__ __forceinline__ void loss_noobj_cell(const L& logit, float* __restric
 
 // A cell that holds an object: responsible predictor by IoU, coordinate,
 // objectness, no-object (other predictors) and class terms with all gradients
-// (model.py:190-294 and their autograd backward).  C_CT > 0 with C_CT % 4 == 0:
-// the class targets are fetched as float4 (gcls 16-byte aligned).  PART 1 does
-// the box and confidence work of the cell only, PART 2 the class work only (the
-// two touch different channels and different sums), PART 0 both.
+// (model.py:190-294 and their autograd backward), by one lane, for a class count
+// known at compile time.  C_CT % 4 == 0: the class targets are fetched as float4
+// (gcls 16-byte aligned).  PART 1 does the box and confidence work of the cell
+// only, PART 2 the class work only (the two touch different channels and
+// different sums), PART 0 both.
 template <int C_CT, int PART = 0, class L>
 __device__ __forceinline__ void loss_obj_cell(const L& logit, float* __restrict__ g,
                                               const float* __restrict__ gxywh,
@@ -85,10 +88,11 @@ __device__ __forceinline__ void loss_obj_cell(const L& logit, float* __restrict_
                                               int S2, int nb, int nc, float cellf, float imgf,
                                               float lc, float ln, float inv_gb, float& acc_coord,
                                               float& acc_conf, float& acc_cls) {
+    static_assert(C_CT > 0, "run-time class counts take loss_obj_cell_wave");
     constexpr bool kBox = PART != 2, kCls = PART != 1;   // which half of the cell's work
     const int c0 = 5 * nb;
-    float gtc[C_CT > 0 ? C_CT : 1];
-    if constexpr (kCls && C_CT > 0 && C_CT % 4 == 0) {
+    float gtc[C_CT];
+    if constexpr (kCls && C_CT % 4 == 0) {
 #pragma unroll
         for (int j = 0; j < C_CT / 4; ++j) {
             const float4 q = reinterpret_cast<const float4*>(gcls)[j];
@@ -96,7 +100,7 @@ __device__ __forceinline__ void loss_obj_cell(const L& logit, float* __restrict_
         }
     }
     auto gtcls = [&](int j) -> float {
-        if constexpr (C_CT > 0 && C_CT % 4 == 0) return gtc[j];
+        if constexpr (C_CT % 4 == 0) return gtc[j];
         else return gcls[j];
     };
     if constexpr (kBox) {
@@ -177,85 +181,191 @@ __device__ __forceinline__ void loss_obj_cell(const L& logit, float* __restrict_
     if constexpr (!kCls) return;
     // class term (model.py:278-294): squared error on the softmax
     float m = logit(c0);
-    if constexpr (C_CT > 0) {
 #pragma unroll
-        for (int j = 1; j < C_CT; ++j) m = fmaxf(m, logit(c0 + j));
-    } else {
-        // run-time class count: eight classes per batch, written out so that the
-        // eight loads of a batch are in flight together (one round trip per batch,
-        // not per class); sums run in class order, as in the compile-time path
-        for (int j0 = 1; j0 < nc; j0 += 8) {
-            float t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = j0 + u < nc ? logit(c0 + j0 + u) : m;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) m = fmaxf(m, t[u]);
-        }
-    }
+    for (int j = 1; j < C_CT; ++j) m = fmaxf(m, logit(c0 + j));
     float s = 0.f, dot = 0.f, l2 = 0.f;
-    if constexpr (C_CT > 0) {
-        // exponentials kept in registers, logits re-read from their (cheap) source
-        float e[C_CT];
+    // exponentials kept in registers, logits re-read from their (cheap) source
+    float e[C_CT];
 #pragma unroll
-        for (int j = 0; j < C_CT; ++j) {
-            e[j] = exp_fast(logit(c0 + j) - m);
-            s += e[j];
+    for (int j = 0; j < C_CT; ++j) {
+        e[j] = exp_fast(logit(c0 + j) - m);
+        s += e[j];
+    }
+    const float rs = rcp_fast(s);
+#pragma unroll
+    for (int j = 0; j < C_CT; ++j) {
+        e[j] *= rs;
+        const float d = e[j] - gtcls(j);
+        l2 += d * d;
+        dot += 2.0f * d * e[j];
+    }
+#pragma unroll
+    for (int j = 0; j < C_CT; ++j)
+        g[(c0 + j) * S2] = e[j] * (2.0f * (e[j] - gtcls(j)) - dot) * inv_gb;
+    acc_cls += l2;
+}
+
+// The same cell, worked on by a group of GW lanes (16 or 32: four or two cells per
+// wavefront at a time, for up to 4 GW classes; 64: a whole wavefront), for run-time predictor
+// and class counts: lane k < nb of the group owns predictor k (its five logits,
+// its IoU with the ground truth, its five gradients; nb <= 16), the classes are
+// spread over the GW lanes.  Every pass over the classes is one memory round
+// trip (four loads per lane in flight) instead of one per class, and the cell
+// costs a few hundred instructions instead of a few thousand executed for a
+// single lane.  The box arithmetic is that of loss_obj_cell, value for value; the
+// softmax sums are formed per lane and then across lanes (the order differs from
+// the one-lane form, the result within rounding).  `p`, `b`, `g`: the cell's
+// channel 0 in the head tensor, the bias and the gradient (channels S2 floats
+// apart).  Every lane of the group must be active.
+template <int GW>
+__device__ __forceinline__ float group_maxf(float v) {
+#pragma unroll
+    for (int o = GW / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+template <int GW>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = GW / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <bool BIAS, int GW>
+__device__ __forceinline__ void loss_obj_cell_wave(
+    const float* __restrict__ p, const float* __restrict__ b, float* __restrict__ g,
+    const float* __restrict__ gxywh, const float* __restrict__ gcls, int cell, int S, int S2,
+    int nb, int nc, float cellf, float imgf, float lc, float ln, float inv_gb, float& acc_coord,
+    float& acc_conf, float& acc_cls) {
+    const int lane = threadIdx.x & (GW - 1);      // position in the group
+    auto logit = [&](int ch) -> float {
+        if constexpr (BIAS) return p[(size_t)ch * S2] + b[(size_t)ch * S2];
+        else return p[(size_t)ch * S2];
+    };
+    // ---- boxes and confidences (model.py:190-276)
+    const float4 gv = *reinterpret_cast<const float4*>(gxywh);
+    const float gnx = gv.x, gny = gv.y, gnw = gv.z, gnh = gv.w;
+    const float xoff = cellf * (float)(cell / S);   // first spatial axis carries x (model.py:175-177)
+    const float yoff = cellf * (float)(cell % S);
+    const Box gbox = decode_box(gnx, gny, gnw, gnh, xoff, yoff, cellf, imgf);
+    float nx = 0.f, ny = 0.f, nw = 0.f, nh = 0.f, conf = 0.f, iou = 0.f;
+    if (lane < nb) {
+        const float l0 = logit(5 * lane), l1 = logit(5 * lane + 1), l2 = logit(5 * lane + 2),
+                    l3 = logit(5 * lane + 3), l4 = logit(5 * lane + 4);
+        nx = sigmoidf_(l0);
+        ny = sigmoidf_(l1);
+        nw = sigmoidf_(l2);
+        nh = sigmoidf_(l3);
+        conf = sigmoidf_(l4);
+        iou = iou_pair_fast(decode_box(nx, ny, nw, nh, xoff, yoff, cellf, imgf), gbox);
+    }
+    // responsible predictor: highest IoU, first index on ties (model.py:210) -- the
+    // one-lane rule, applied to the lanes' values in predictor order
+    int best = 0;
+    float biou = __shfl(iou, 0, GW);
+    for (int k = 1; k < nb; ++k) {
+        const float v = __shfl(iou, k, GW);
+        if (v > biou) { best = k; biou = v; }
+    }
+    if (lane < nb) {
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, gc;
+        if (lane == best) {
+            // coordinate term (model.py:224-240)
+            const float dx = nx - gnx, dy = ny - gny;
+            const float sw = __builtin_amdgcn_sqrtf(nw), sh = __builtin_amdgcn_sqrtf(nh);
+            const float dw = sw - __builtin_amdgcn_sqrtf(gnw), dh = sh - __builtin_amdgcn_sqrtf(gnh);
+            acc_coord += lc * ((dx * dx + dy * dy) + (dw * dw + dh * dh));
+            const float r0 = 2.0f * lc * dx;
+            const float r1 = 2.0f * lc * dy;
+            const float r2 = lc * dw * sw * (1.0f - nw);
+            const float r3 = lc * dh * sh * (1.0f - nh);
+            // objectness term; IoU is part of the graph (model.py:263-269)
+            const float dc = conf - iou;
+            acc_conf += dc * dc;
+            float ul, ut, ur, ub, gl, gt, gr, gb;
+            const Box pb = decode_box(nx, ny, nw, nh, xoff, yoff, cellf, imgf, ul, ut, ur, ub);
+            iou_pair_bwd(pb, gbox, -2.0f * dc, gl, gt, gr, gb);
+            gl = ul >= 0.0f ? gl : 0.0f;     // xywh_to_ltrb backward: a clipped edge passes nothing
+            gt = ut >= 0.0f ? gt : 0.0f;
+            gr = ur <= imgf ? gr : 0.0f;
+            gb = ub <= imgf ? gb : 0.0f;
+            const float gx_iou = (gl + gr) * cellf;
+            const float gy_iou = (gt + gb) * cellf;
+            const float gw_iou = (gr - gl) * 0.5f * imgf;
+            const float gh_iou = (gb - gt) * 0.5f * imgf;
+            g0 = (r0 + gx_iou) * (nx * (1.0f - nx));
+            g1 = (r1 + gy_iou) * (ny * (1.0f - ny));
+            g2 = r2 + gw_iou * (nw * (1.0f - nw));
+            g3 = r3 + gh_iou * (nh * (1.0f - nh));
+            gc = 2.0f * dc * (conf * (1.0f - conf));
+        } else {
+            // the other predictors of the cell carry the no-object term (model.py:270-274)
+            acc_conf += ln * (conf * conf);
+            gc = 2.0f * ln * conf * (conf * (1.0f - conf));
         }
-        const float rs = rcp_fast(s);
+        float* q = g + (size_t)(5 * lane) * S2;
+        q[0] = g0 * inv_gb;
+        q[S2] = g1 * inv_gb;
+        q[2 * (size_t)S2] = g2 * inv_gb;
+        q[3 * (size_t)S2] = g3 * inv_gb;
+        q[4 * (size_t)S2] = gc * inv_gb;
+    }
+    // ---- classes (model.py:278-294): squared error on the softmax, class j0 + GW u by lane j0
+    const int c0 = 5 * nb;
+    float m = logit(c0);
+    for (int j0 = lane; j0 < nc; j0 += 4 * GW) {
+        float t[4];
 #pragma unroll
-        for (int j = 0; j < C_CT; ++j) {
-            e[j] *= rs;
-            const float d = e[j] - gtcls(j);
-            l2 += d * d;
-            dot += 2.0f * d * e[j];
+        for (int u = 0; u < 4; ++u) t[u] = j0 + GW * u < nc ? logit(c0 + j0 + GW * u) : m;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m = fmaxf(m, t[u]);
+    }
+    m = group_maxf<GW>(m);
+    float s = 0.f;
+    for (int j0 = lane; j0 < nc; j0 += 4 * GW) {
+        float t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = j0 + GW * u < nc ? logit(c0 + j0 + GW * u) : m;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j0 + GW * u < nc) s += exp_fast(t[u] - m);
+    }
+    s = group_sum<GW>(s);
+    const float rs = rcp_fast(s);
+    float dot = 0.f, l2 = 0.f;
+    for (int j0 = lane; j0 < nc; j0 += 4 * GW) {
+        float t[4], q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            t[u] = j0 + GW * u < nc ? logit(c0 + j0 + GW * u) : m;
+            q[u] = j0 + GW * u < nc ? gcls[j0 + GW * u] : 0.0f;
         }
 #pragma unroll
-        for (int j = 0; j < C_CT; ++j)
-            g[(c0 + j) * S2] = e[j] * (2.0f * (e[j] - gtcls(j)) - dot) * inv_gb;
-    } else {
-        for (int j0 = 0; j0 < nc; j0 += 8) {
-            float t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = j0 + u < nc ? logit(c0 + j0 + u) : m;
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (j0 + u < nc) s += exp_fast(t[u] - m);
-        }
-        const float rs = rcp_fast(s);
-        for (int j0 = 0; j0 < nc; j0 += 8) {
-            float t[8], q[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                t[u] = j0 + u < nc ? logit(c0 + j0 + u) : m;
-                q[u] = j0 + u < nc ? gtcls(j0 + u) : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (j0 + u < nc) {
-                    const float pj = exp_fast(t[u] - m) * rs;
-                    const float d = pj - q[u];
-                    l2 += d * d;
-                    dot += 2.0f * d * pj;
-                }
-            }
-        }
-        for (int j0 = 0; j0 < nc; j0 += 8) {
-            float t[8], q[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                t[u] = j0 + u < nc ? logit(c0 + j0 + u) : m;
-                q[u] = j0 + u < nc ? gtcls(j0 + u) : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (j0 + u < nc) {
-                    const float pj = exp_fast(t[u] - m) * rs;
-                    g[(c0 + j0 + u) * S2] = pj * (2.0f * (pj - q[u]) - dot) * inv_gb;
-                }
+        for (int u = 0; u < 4; ++u) {
+            if (j0 + GW * u < nc) {
+                const float pj = exp_fast(t[u] - m) * rs;
+                const float d = pj - q[u];
+                l2 += d * d;
+                dot += 2.0f * d * pj;
             }
         }
     }
-    acc_cls += l2;
+    dot = group_sum<GW>(dot);
+    acc_cls += l2;     // per lane; the workgroup reduction adds the lanes
+    for (int j0 = lane; j0 < nc; j0 += 4 * GW) {
+        float t[4], q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            t[u] = j0 + GW * u < nc ? logit(c0 + j0 + GW * u) : m;
+            q[u] = j0 + GW * u < nc ? gcls[j0 + GW * u] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j0 + GW * u < nc) {
+                const float pj = exp_fast(t[u] - m) * rs;
+                g[(size_t)(c0 + j0 + GW * u) * S2] = pj * (2.0f * (pj - q[u]) - dot) * inv_gb;
+            }
+        }
+    }
 }
 
 // reads a cell's channels from the head tensor on use
@@ -412,22 +522,73 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
     const int S2 = S * S;
     const long long D = 5 * nb + nc;
     const long long img0 = (long long)bid * imgs_per_block;
-    const int nitems = imgs_per_block * S2;
+    const int nitems = imgs_per_block * S2;       // <= max(LOSS_THREADS, YH_MAX_S^2) = 4096
+    // Pass 1, one lane per cell: a cell without an object is finished (its confidence
+    // logits in, D gradients out); a cell with one is listed, per wavefront and in
+    // cell order, so that the order of every sum is the same from run to run.
+    // Pass 2: the listed cells, a group of lanes per cell (loss_obj_cell_wave): 16 or
+    // 32 lanes while they cover the classes in one batch of loads, else a wavefront.
+    constexpr int NW = LOSS_THREADS / 64;
+    constexpr int LIST_CAP = 4096 / NW;           // items a wavefront can see: 64 per round
+    __shared__ unsigned short olist[NW][LIST_CAP];
+    __shared__ int wcount[NW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float acc_coord = 0.f, acc_conf = 0.f, acc_cls = 0.f;
-    for (int item = threadIdx.x; item < nitems; item += LOSS_THREADS) {
-        const int gi = item / S2;
-        const int cell = item - gi * S2;
-        const long long img = img0 + gi;
-        if (img < batch) {
+    int listed = 0;                               // wave-uniform
+    for (int item0 = 0; item0 < nitems; item0 += LOSS_THREADS) {
+        const int item = item0 + threadIdx.x;
+        bool has_obj = false;
+        if (item < nitems) {
+            const int gi = item / S2;
+            const int cell = item - gi * S2;
+            const long long img = img0 + gi;
+            if (img < batch) {
+                has_obj = obj_mask[img * S2 + cell] != 0;
+                if (!has_obj) {
+                    const long long off = img * D * S2 + cell;
+                    const GlobalLogits<BIAS> logit{pred + off, BIAS ? bias + cell : nullptr, S2};
+                    loss_noobj_cell_rt(logit, grad + off, S2, nb, nc, ln, inv_gb, acc_conf);
+                }
+            }
+        }
+        const unsigned long long om = __ballot(has_obj);
+        if (has_obj)
+            olist[wave][listed + __popcll(om & ((1ull << lane) - 1ull))] = (unsigned short)item;
+        listed += __popcll(om);
+    }
+    if (lane == 0) wcount[wave] = listed;
+    __syncthreads();
+    {
+        int cnt[NW];
+        int total_obj = 0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) { cnt[q] = wcount[q]; total_obj += cnt[q]; }
+        auto listed_cell = [&](int j0, auto gw) {
+            constexpr int GW = decltype(gw)::value;
+            int j = j0, src = 0;
+#pragma unroll
+            for (int q = 0; q < NW - 1; ++q)
+                if (src == q && j >= cnt[q]) { j -= cnt[q]; src = q + 1; }
+            const int item = olist[src][j];
+            const int gi = item / S2;
+            const int cell = item - gi * S2;
+            const long long img = img0 + gi;
             const long long tcell = img * S2 + cell;
             const long long off = img * D * S2 + cell;
-            const GlobalLogits<BIAS> logit{pred + off, BIAS ? bias + cell : nullptr, S2};
-            if (obj_mask[tcell] != 0)
-                loss_obj_cell<0>(logit, grad + off, gt_xywh + tcell * 4, gt_cls + tcell * nc, cell,
-                                 S, S2, nb, nc, cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf,
-                                 acc_cls);
-            else
-                loss_noobj_cell_rt(logit, grad + off, S2, nb, nc, ln, inv_gb, acc_conf);
+            loss_obj_cell_wave<BIAS, GW>(pred + off, BIAS ? bias + cell : nullptr, grad + off,
+                                         gt_xywh + tcell * 4, gt_cls + tcell * nc, cell, S, S2, nb,
+                                         nc, cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf,
+                                         acc_cls);
+        };
+        if (nc <= 64) {
+            for (int j0 = (int)threadIdx.x / 16; j0 < total_obj; j0 += LOSS_THREADS / 16)
+                listed_cell(j0, std::integral_constant<int, 16>{});
+        } else if (nc <= 128) {
+            for (int j0 = (int)threadIdx.x / 32; j0 < total_obj; j0 += LOSS_THREADS / 32)
+                listed_cell(j0, std::integral_constant<int, 32>{});
+        } else {
+            for (int j0 = wave; j0 < total_obj; j0 += NW)
+                listed_cell(j0, std::integral_constant<int, 64>{});
         }
     }
     loss_block_reduce(acc_coord, acc_conf, acc_cls, partials, bid);
