@@ -194,9 +194,33 @@ __device__ __forceinline__ uint32_t float_to_ordered(float f) {
 }
 
 // ---- wave64 helpers -----------------------------------------------------------
+// Lane i of a row of 16 receives the value of lane perm(i) of the same row through
+// the data-parallel-primitive path of the VALU (no LDS round trip): quad_perm
+// [1,0,3,2] and [2,3,0,1] are lane ^ 1 and lane ^ 2, row_half_mirror is 7 - i within
+// each half row, row_mirror is 15 - i.  Every lane of the row must be active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// sum / maximum over each row of 16 lanes, delivered to all 16
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_row<0xB1>(v);
+    v += dpp_row<0x4E>(v);
+    v += dpp_row<0x141>(v);
+    v += dpp_row<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_maxf(float v) {
+    v = fmaxf(v, dpp_row<0xB1>(v));
+    v = fmaxf(v, dpp_row<0x4E>(v));
+    v = fmaxf(v, dpp_row<0x141>(v));
+    v = fmaxf(v, dpp_row<0x140>(v));
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = row16_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ __forceinline__ int wave_max(int v) {

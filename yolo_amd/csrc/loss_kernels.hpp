@@ -219,28 +219,34 @@ __device__ __forceinline__ void loss_obj_cell(const L& logit, float* __restrict_
 // apart).  Every lane of the group must be active.
 template <int GW>
 __device__ __forceinline__ float group_maxf(float v) {
+    v = row16_maxf(v);
 #pragma unroll
-    for (int o = GW / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    for (int o = 16; o < GW; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
 template <int GW>
 __device__ __forceinline__ float group_sum(float v) {
+    v = row16_sum(v);
 #pragma unroll
-    for (int o = GW / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = 16; o < GW; o <<= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
-template <bool BIAS, int GW>
+template <int GW, class L>
 __device__ __forceinline__ void loss_obj_cell_wave(
-    const float* __restrict__ p, const float* __restrict__ b, float* __restrict__ g,
-    const float* __restrict__ gxywh, const float* __restrict__ gcls, int cell, int S, int S2,
-    int nb, int nc, float cellf, float imgf, float lc, float ln, float inv_gb, float& acc_coord,
-    float& acc_conf, float& acc_cls) {
+    const L& logit, float* g, const float* __restrict__ gxywh, const float* __restrict__ gcls,
+    int cell, int S, int S2, int nb, int nc, float cellf, float imgf, float lc, float ln,
+    float inv_gb, float& acc_coord, float& acc_conf, float& acc_cls) {
     const int lane = threadIdx.x & (GW - 1);      // position in the group
-    auto logit = [&](int ch) -> float {
-        if constexpr (BIAS) return p[(size_t)ch * S2] + b[(size_t)ch * S2];
-        else return p[(size_t)ch * S2];
-    };
+    const int c0 = 5 * nb;
+    // everything the cell needs from memory is requested here, in one round trip
+    float t0[4], q0[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = lane + GW * u;
+        t0[u] = j < nc ? logit(c0 + j) : 0.0f;
+        q0[u] = j < nc ? gcls[j] : 0.0f;
+    }
     // ---- boxes and confidences (model.py:190-276)
     const float4 gv = *reinterpret_cast<const float4*>(gxywh);
     const float gnx = gv.x, gny = gv.y, gnw = gv.z, gnh = gv.w;
@@ -309,10 +315,14 @@ __device__ __forceinline__ void loss_obj_cell_wave(
         q[3 * (size_t)S2] = g3 * inv_gb;
         q[4 * (size_t)S2] = gc * inv_gb;
     }
-    // ---- classes (model.py:278-294): squared error on the softmax, class j0 + GW u by lane j0
-    const int c0 = 5 * nb;
-    float m = logit(c0);
-    for (int j0 = lane; j0 < nc; j0 += 4 * GW) {
+    // ---- classes (model.py:278-294): squared error on the softmax, class j0 + GW u by
+    // lane j0.  The first 4 GW classes sit in registers (t0, q0: fetched on entry);
+    // a cell with more re-reads the rest in every pass.
+    float m = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (lane + GW * u < nc) m = fmaxf(m, t0[u]);
+    for (int j0 = lane + 4 * GW; j0 < nc; j0 += 4 * GW) {
         float t[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) t[u] = j0 + GW * u < nc ? logit(c0 + j0 + GW * u) : m;
@@ -321,7 +331,12 @@ __device__ __forceinline__ void loss_obj_cell_wave(
     }
     m = group_maxf<GW>(m);
     float s = 0.f;
-    for (int j0 = lane; j0 < nc; j0 += 4 * GW) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        t0[u] = exp_fast(t0[u] - m);              // from here on: the exponentials
+        if (lane + GW * u < nc) s += t0[u];
+    }
+    for (int j0 = lane + 4 * GW; j0 < nc; j0 += 4 * GW) {
         float t[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) t[u] = j0 + GW * u < nc ? logit(c0 + j0 + GW * u) : m;
@@ -332,7 +347,16 @@ __device__ __forceinline__ void loss_obj_cell_wave(
     s = group_sum<GW>(s);
     const float rs = rcp_fast(s);
     float dot = 0.f, l2 = 0.f;
-    for (int j0 = lane; j0 < nc; j0 += 4 * GW) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        t0[u] *= rs;                              // the probabilities
+        if (lane + GW * u < nc) {
+            const float d = t0[u] - q0[u];
+            l2 += d * d;
+            dot += 2.0f * d * t0[u];
+        }
+    }
+    for (int j0 = lane + 4 * GW; j0 < nc; j0 += 4 * GW) {
         float t[4], q[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -351,7 +375,11 @@ __device__ __forceinline__ void loss_obj_cell_wave(
     }
     dot = group_sum<GW>(dot);
     acc_cls += l2;     // per lane; the workgroup reduction adds the lanes
-    for (int j0 = lane; j0 < nc; j0 += 4 * GW) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (lane + GW * u < nc)
+            g[(size_t)(c0 + lane + GW * u) * S2] = t0[u] * (2.0f * (t0[u] - q0[u]) - dot) * inv_gb;
+    for (int j0 = lane + 4 * GW; j0 < nc; j0 += 4 * GW) {
         float t[4], q[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -575,10 +603,10 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
             const long long img = img0 + gi;
             const long long tcell = img * S2 + cell;
             const long long off = img * D * S2 + cell;
-            loss_obj_cell_wave<BIAS, GW>(pred + off, BIAS ? bias + cell : nullptr, grad + off,
-                                         gt_xywh + tcell * 4, gt_cls + tcell * nc, cell, S, S2, nb,
-                                         nc, cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf,
-                                         acc_cls);
+            const GlobalLogits<BIAS> logit{pred + off, BIAS ? bias + cell : nullptr, S2};
+            loss_obj_cell_wave<GW>(logit, grad + off, gt_xywh + tcell * 4, gt_cls + tcell * nc,
+                                   cell, S, S2, nb, nc, cellf, imgf, lc, ln, inv_gb, acc_coord,
+                                   acc_conf, acc_cls);
         };
         if (nc <= 64) {
             for (int j0 = (int)threadIdx.x / 16; j0 < total_obj; j0 += LOSS_THREADS / 16)
