@@ -458,7 +458,6 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             heads[e] = __ballot(al[e] && (e * NT + lane == 0 || c != pc));
             prev_last = __shfl(c, 63, 64);
         }
-        int mp = 0;
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
             const unsigned long long mine = heads[e] & ((2ull << lane) - 1ull);
@@ -467,9 +466,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             for (int q = ITEMS - 1; q >= 0; --q)
                 if (q < e && sg < 0 && heads[q]) sg = q * NT + 63 - __clzll(heads[q]);
             mymeta[e].w = al[e] ? sg : 0;
-            mp = max(mp, al[e] ? e * NT + lane - sg : 0);
         }
-        maxpos = wave_max(mp);
     }
     int pos_out[ITEMS];   // output row of a survivor
     int total = 0;        // survivors of the image
@@ -478,7 +475,13 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         unsigned long long aw[ITEMS];
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) aw[e] = __ballot(al[e]);
-        for (int step = 0; step < maxpos; ++step) {
+        // a step is needed while some candidate that is still alive has a member of its
+        // segment left to be tested against (one ballot; no longest-segment reduction)
+        for (int step = 0;; ++step) {
+            bool more = false;
+#pragma unroll
+            for (int e = 0; e < ITEMS; ++e) more |= al[e] && e * NT + t - mymeta[e].w > step;
+            if (!__ballot(more)) break;
 #pragma unroll
             for (int e = 0; e < ITEMS; ++e) {
                 const int i = e * NT + t;
