@@ -92,12 +92,35 @@ def test_no_objects_and_all_objects(dev):
     check_against_oracle(terms, grad, ref_cpu.loss_and_grad(pred, gx_all, gc_all, om_all))
 
 
+def test_every_cell_holds_an_object_run_time_shapes(dev):
+    """The run-time-shape kernel lists the cells that hold an object per wavefront and
+    works on them group by group: here every cell is listed (the lists are full), with
+    more cells than threads in a workgroup in the second shape, and the ground truth is
+    a distribution over the classes, not a one-hot row."""
+    for S, Bx, C, batch in ((9, 3, 7, 5), (17, 2, 70, 2), (20, 1, 130, 1)):
+        img = 32 * S
+        head = YOLOv1Head(img_size=img, n_cells=S, n_bboxes=Bx, n_classes=C)
+        pred = synth.make_pred(batch, S, Bx, C, seed=S)
+        g = torch.Generator().manual_seed(S)
+        gx = torch.rand(batch, S * S, 1, 4, generator=g) * 0.9 + 0.05
+        gc = torch.softmax(torch.randn(batch, S * S, 1, C, generator=g) * 3, dim=-1)
+        om = torch.ones(batch, S * S, 1, 1, dtype=torch.bool)
+        terms, grad = run_hip(head, dev, pred, gx, gc, om)
+        check_against_oracle(terms, grad, ref_cpu.loss_and_grad(pred, gx, gc, om, **hp_of(head)))
+
+
 @pytest.mark.parametrize("S,Bx,C,img,batch", [
     (14, 5, 80, 448, 3),     # the NMS stress shape also runs through the loss
     (3, 1, 4, 96, 9),
     (7, 3, 20, 448, 6),
     (7, 2, 21, 448, 5),      # class count not a multiple of 4
     (17, 2, 5, 34 * 17, 2),  # more cells than threads in a workgroup
+    (5, 16, 3, 160, 7),      # sixteen predictors: every lane of a 16-lane group owns one
+    (6, 16, 64, 192, 4),     # 64 classes: the largest count a 16-lane group takes
+    (6, 2, 65, 192, 4),      # 65: the first for 32-lane groups
+    (4, 3, 128, 128, 5),     # 128: the last for 32-lane groups
+    (4, 1, 129, 128, 5),     # 129: a wavefront per cell
+    (3, 2, 700, 96, 3),      # more classes than one batch of loads per wavefront covers
 ])
 def test_other_shapes(dev, S, Bx, C, img, batch):
     head = YOLOv1Head(img_size=img, n_cells=S, n_bboxes=Bx, n_classes=C)
