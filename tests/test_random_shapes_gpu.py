@@ -5,7 +5,9 @@ oracle on the same candidates, bit for bit), and the target encoder (bit for
 bit).  The shapes are drawn so that every launch variant is hit: one wavefront
 per image with one or two candidates per lane, one workgroup per image with
 1, 2 or 4 candidates per thread, class counts that are and are not multiples
-of four, more cells than threads in a workgroup."""
+of four, more cells than threads in a workgroup.  YH_SWEEP_CONFIGS sets the
+number of configurations, YH_SWEEP_WIDE=1 widens the ranges (grids up to 30,
+16 predictors, 300 classes, 2,048 candidates)."""
 import os
 
 import numpy as np
@@ -21,11 +23,13 @@ pytestmark = pytest.mark.gpu
 def configs():
     rng = np.random.default_rng(20240607)
     out = []
+    wide = os.environ.get("YH_SWEEP_WIDE") == "1"     # larger grids, up to 16 predictors, more classes
     while len(out) < int(os.environ.get("YH_SWEEP_CONFIGS", "64")):
-        S = int(rng.integers(1, 15))
-        Bx = int(rng.integers(1, 6))
-        C = int(rng.choice([1, 2, 3, 4, 7, 20, 21, 33, 80, 100]))
-        if S * S * Bx > 1024:
+        S = int(rng.integers(1, 31 if wide else 15))
+        Bx = int(rng.integers(1, 17 if wide else 6))
+        C = int(rng.choice([1, 2, 3, 4, 7, 20, 21, 33, 64, 65, 80, 128, 129, 300] if wide
+                           else [1, 2, 3, 4, 7, 20, 21, 33, 80, 100]))
+        if S * S * Bx > 2048:
             continue
         batch = int(rng.choice([1, 2, 3, 5, 9, 17]))
         mode = int(rng.integers(0, 2))
