@@ -14,6 +14,6 @@ for total_mb in (33.7, 52.0, 67.6, 135.0, 540.0, 2000.0, 8000.0):
     n = int(total_mb * 1e6 / 2 / 4)
     x = torch.randn(n, device=dev); y = torch.empty_like(x)
     us = timeit(lambda: y.copy_(x))
-    print(f"copy {total_mb:6.1f} MB total traffic: {us:7.2f} us  -> {total_mb*1e6/us/1e6:7.1f} GB/s")
+    print(f"copy {total_mb:6.1f} MB total traffic: {us:7.2f} us  -> {total_mb / us:7.2f} TB/s")
     us = timeit(lambda: y.zero_())
-    print(f"fill {total_mb/2:6.1f} MB written      : {us:7.2f} us  -> {total_mb/2*1e6/us/1e6:7.1f} GB/s")
+    print(f"fill {total_mb/2:6.1f} MB written      : {us:7.2f} us  -> {total_mb / 2 / us:7.2f} TB/s")
