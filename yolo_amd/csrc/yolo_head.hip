@@ -406,8 +406,17 @@ int yh_pairwise_boxes(const float* ltrb1, const float* ltrb2, float* out, int64_
     if (bx > 64) bx = 64;
     int64_t by = 4096 / bx;   // about 4096 workgroups in all; each loops over its share of the rows
     if (by > N) by = N;
-    hipLaunchKernelGGL(yh::pairwise_boxes_kernel, dim3((unsigned)bx, (unsigned)by), dim3(256), 0,
-                       (hipStream_t)stream, ltrb1, ltrb2, out, (long long)N, (long long)M, kind);
+    const dim3 grid((unsigned)bx, (unsigned)by);
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == YH_BOX_IOU)
+        hipLaunchKernelGGL(yh::pairwise_boxes_kernel<yh::BOX_IOU>, grid, dim3(256), 0, st, ltrb1,
+                           ltrb2, out, (long long)N, (long long)M);
+    else if (kind == YH_BOX_GIOU)
+        hipLaunchKernelGGL(yh::pairwise_boxes_kernel<yh::BOX_GIOU>, grid, dim3(256), 0, st, ltrb1,
+                           ltrb2, out, (long long)N, (long long)M);
+    else
+        hipLaunchKernelGGL(yh::pairwise_boxes_kernel<yh::BOX_INTERSECTION>, grid, dim3(256), 0, st,
+                           ltrb1, ltrb2, out, (long long)N, (long long)M);
     return launch_status();
 }
 
