@@ -69,14 +69,18 @@ __global__ __launch_bounds__(256) void encode_targets_tiled_kernel(
     for (int i = threadIdx.x; i < nimg * M; i += 256) {
         const int gi = i / M, m = i - gi * M;
         const long long img = img0 + gi;
+        // the box and its label are requested together with the count, not after it: the
+        // rows beyond the count are padding, but they exist
         int n = gt_count[img];
+        const float4 box = reinterpret_cast<const float4*>(gt_ltrb)[img * M + m];
+        const int label = gt_label[img * M + m];
         n = n < 0 ? 0 : (n > M ? M : n);
         int cell = -1;
         if (m < n) {
             float4 norm;
-            cell = encode_box(reinterpret_cast<const float4*>(gt_ltrb)[img * M + m], S, cellf, imgf, norm);
+            cell = encode_box(box, S, cellf, imgf, norm);
             e_norm[i] = norm;
-            e_label[i] = gt_label[img * M + m];
+            e_label[i] = label;
         }
         e_cell[i] = cell;
     }
