@@ -9,11 +9,15 @@
 //      lower class (the start of its class segment) from broadcast LDS reads
 //   C  scatter to rank order in LDS: classes become contiguous segments, each
 //      in descending score order
-//   D  greedy suppression, all classes at once: in step s every candidate looks
-//      at the s-th member of its own segment (the pivot); if the pivot is still
-//      alive and IoU > threshold the candidate dies.  Liveness is a bitmask in
-//      LDS rebuilt with one ballot per wavefront per step, so a pivot's bit is
-//      final before it is used.  The step count is the longest segment - 1.
+//   D  greedy suppression, all classes at once.  One wavefront per image: in step
+//      s every candidate looks at the s-th member of its own segment (the pivot);
+//      if the pivot is still alive and IoU > threshold the candidate dies.
+//      Liveness is one 64-bit ballot per 64 positions, held in scalar registers
+//      and rebuilt after every step, so a pivot's bit is final before it is
+//      used; the loop ends when no live candidate has a pivot left.  One
+//      workgroup per image: every (earlier, later) pair of every segment is
+//      tested once, the pairs spread evenly over the threads, and a lane per
+//      segment then resolves the kill sets in order (see the code).
 //   E  kept rows get their output slot from a prefix popcount over the
 //      liveness words and are stored straight from registers (consecutive
 //      survivors write consecutive 24-byte rows); the tail is zero-filled.
