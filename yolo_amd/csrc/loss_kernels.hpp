@@ -1,11 +1,16 @@
 // Fused YOLOv1 loss forward + backward (model.py:190-317 and its autograd
-// backward).  One lane owns one grid cell of one image: it reads the cell's D
-// logits (stride S*S apart in the channel-major head tensor, so consecutive
-// lanes read consecutive addresses), the cell's ground truth, evaluates the
-// three loss terms and writes the cell's D gradients.  Loss partials are
-// reduced wave -> workgroup -> one row of `partials` per workgroup; a second
-// tiny kernel adds the rows in a fixed order, so results are reproducible bit
-// for bit.
+// backward).  The head tensor is channel-major, so with one lane per grid cell
+// consecutive lanes read and write consecutive addresses of a channel.  Two
+// passes per workgroup: pass 1, a lane per cell, finishes the cells without an
+// object (their confidence logits in, their gradients out) and lists the cells
+// that hold one; pass 2 works on the listed cells only -- a few lanes per
+// workgroup in the compile-time-shape kernel, a group of lanes per cell in the
+// run-time-shape kernel -- so the long object path is not executed by every
+// wavefront for one or two of its lanes.  All gradients are analytic.  Loss
+// partials are reduced wave -> workgroup -> one row of `partials` per workgroup
+// and the rows are added in a fixed order in fp64 (by a second tiny kernel, or
+// by the first workgroup of the next call), so results are reproducible bit for
+// bit.
 #pragma once
 #include <type_traits>
 
