@@ -535,7 +535,18 @@ __device__ __forceinline__ void loss_pipe_log(const LossPipe& p, int own_rows, f
 // Run-time shape (any S, Bx, C within the limits): channels are read on use.
 // BIAS: `pred` is the last layer's output before its bias (model.py:133-135) and
 // `bias` (one image's worth of values, same layout) is added as the logits are read.
-template <bool PIPE, bool BIAS>
+// TILE: the workgroup's gradients -- one contiguous block of the tensor -- are
+// collected in LDS (dynamic, loss_generic_tile_floats() floats) and leave in
+// 16-byte stores; `grad` must be 16-byte aligned and the workgroup must own at
+// most LOSS_TILE_MAX_ITEMS cells.  Otherwise every lane stores its cell's
+// gradients directly, channel by channel.
+constexpr int LOSS_TILE_MAX_ITEMS = 1024;
+constexpr int LOSS_TILE_MAX_BYTES = 38 * 1024;    // four workgroups per CU with the lists
+inline long long loss_generic_tile_floats(int imgs_per_block, int S, int nb, int nc) {
+    return (long long)imgs_per_block * (5 * nb + nc) * S * S + 4;
+}
+
+template <bool PIPE, bool BIAS, bool TILE>
 __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
     const float* __restrict__ pred, const float* __restrict__ bias,
     const float* __restrict__ gt_xywh,
@@ -562,8 +573,14 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
     // Pass 2: the listed cells, a group of lanes per cell (loss_obj_cell_wave): 16 or
     // 32 lanes while they cover the classes in one batch of loads, else a wavefront.
     constexpr int NW = LOSS_THREADS / 64;
-    constexpr int LIST_CAP = 4096 / NW;           // items a wavefront can see: 64 per round
+    // items a wavefront can see: 64 per round
+    constexpr int LIST_CAP = (TILE ? LOSS_TILE_MAX_ITEMS : 4096) / NW;
     __shared__ unsigned short olist[NW][LIST_CAP];
+    extern __shared__ __attribute__((aligned(16))) float gtile[];   // TILE only
+    // `pad` lines the LDS copy up with the 16-byte grid of the global addresses
+    const long long gbase = img0 * D * S2;
+    const int pad = TILE ? (int)(gbase & 3) : 0;
+    const int DS2 = (int)D * S2;
     __shared__ int wcount[NW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float acc_coord = 0.f, acc_conf = 0.f, acc_cls = 0.f;
@@ -580,7 +597,9 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
                 if (!has_obj) {
                     const long long off = img * D * S2 + cell;
                     const GlobalLogits<BIAS> logit{pred + off, BIAS ? bias + cell : nullptr, S2};
-                    loss_noobj_cell_rt(logit, grad + off, S2, nb, nc, ln, inv_gb, acc_conf);
+                    float* g = grad + off;
+                    if constexpr (TILE) g = gtile + pad + gi * DS2 + cell;
+                    loss_noobj_cell_rt(logit, g, S2, nb, nc, ln, inv_gb, acc_conf);
                 }
             }
         }
@@ -609,9 +628,11 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
             const long long tcell = img * S2 + cell;
             const long long off = img * D * S2 + cell;
             const GlobalLogits<BIAS> logit{pred + off, BIAS ? bias + cell : nullptr, S2};
-            loss_obj_cell_wave<GW>(logit, grad + off, gt_xywh + tcell * 4, gt_cls + tcell * nc,
-                                   cell, S, S2, nb, nc, cellf, imgf, lc, ln, inv_gb, acc_coord,
-                                   acc_conf, acc_cls);
+            float* g = grad + off;
+            if constexpr (TILE) g = gtile + pad + gi * DS2 + cell;
+            loss_obj_cell_wave<GW>(logit, g, gt_xywh + tcell * 4, gt_cls + tcell * nc, cell, S, S2,
+                                   nb, nc, cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf,
+                                   acc_cls);
         };
         if (nc <= 64) {
             for (int j0 = (int)threadIdx.x / 16; j0 < total_obj; j0 += LOSS_THREADS / 16)
@@ -624,7 +645,21 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
                 listed_cell(j0, std::integral_constant<int, 64>{});
         }
     }
-    loss_block_reduce(acc_coord, acc_conf, acc_cls, partials, bid);
+    loss_block_reduce(acc_coord, acc_conf, acc_cls, partials, bid);   // has a barrier after the LDS writes
+    if constexpr (TILE) {
+        const long long left = batch - img0;
+        const int n = (int)(left < imgs_per_block ? left : imgs_per_block) * DS2;   // floats of this block
+        float* gout = grad + gbase;
+        const int head = (4 - pad) & 3;                             // floats up to the 16-byte grid
+        if ((int)threadIdx.x < head && (int)threadIdx.x < n)
+            gout[threadIdx.x] = gtile[pad + threadIdx.x];
+        const int n4 = n > head ? (n - head) >> 2 : 0;
+        const float4* s4 = reinterpret_cast<const float4*>(gtile + pad + head);
+        float4* g4 = reinterpret_cast<float4*>(gout + head);
+        for (int i = threadIdx.x; i < n4; i += LOSS_THREADS) g4[i] = s4[i];
+        const int done = head + 4 * n4;
+        if ((int)threadIdx.x < n - done) gout[done + threadIdx.x] = gtile[pad + done + threadIdx.x];
+    }
 }
 
 // Compile-time shape.  A lane keeps the logits it needs in registers; with S*S

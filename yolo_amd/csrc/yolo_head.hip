@@ -188,6 +188,16 @@ int loss_launch(const float* pred, const float* bias, const float* gt_xywh, cons
     const bool fast = S == 7 && Bx == 2 && C == 20 && aligned(gt_cls, 16) && aligned(grad_pred, 16);
     const yh::LossPipe pp = pipe ? *pipe : yh::LossPipe{};
     const dim3 grid((unsigned)(rows + (pipe ? 1 : 0)));
+    // run-time shapes: the gradients of a workgroup go through an LDS tile when they fit
+    const long long tile_bytes = yh::loss_generic_tile_floats(g, S, Bx, C) * 4;
+    const bool tile = !fast && aligned(grad_pred, 16) && tile_bytes <= yh::LOSS_TILE_MAX_BYTES &&
+                      g * S * S <= yh::LOSS_TILE_MAX_ITEMS;
+    const size_t lds = tile ? (size_t)tile_bytes : 0;
+#define YH_LOSS_GENERIC(PIPE, BIAS, TILE)                                                        \
+    hipLaunchKernelGGL((yh::loss_fwd_bwd_generic_kernel<PIPE, BIAS, TILE>), grid,                \
+                       dim3(yh::LOSS_THREADS), lds, st, pred, bias, gt_xywh, gt_cls, obj_mask,   \
+                       grad_pred, rows_base, (long long)batch, S, Bx, C, g, cellf, imgf,         \
+                       lambda_coord, lambda_noobj, inv_global_batch, pp);
 #define YH_LOSS_LAUNCH(PIPE)                                                                     \
     if (fast && bias)                                                                            \
         hipLaunchKernelGGL((yh::loss_fwd_bwd_kernel<7, 2, 20, PIPE, true>), grid,                \
@@ -199,18 +209,17 @@ int loss_launch(const float* pred, const float* bias, const float* gt_xywh, cons
                            dim3(yh::LOSS_THREADS), 0, st, pred, bias, gt_xywh, gt_cls, obj_mask, \
                            grad_pred, rows_base, (long long)batch, g, cellf, imgf, lambda_coord, \
                            lambda_noobj, inv_global_batch, pp);                                  \
+    else if (bias && tile)                                                                       \
+        YH_LOSS_GENERIC(PIPE, true, true)                                                        \
     else if (bias)                                                                               \
-        hipLaunchKernelGGL((yh::loss_fwd_bwd_generic_kernel<PIPE, true>), grid,                  \
-                           dim3(yh::LOSS_THREADS), 0, st, pred, bias, gt_xywh, gt_cls, obj_mask, \
-                           grad_pred, rows_base, (long long)batch, S, Bx, C, g, cellf, imgf,     \
-                           lambda_coord, lambda_noobj, inv_global_batch, pp);                    \
+        YH_LOSS_GENERIC(PIPE, true, false)                                                       \
+    else if (tile)                                                                               \
+        YH_LOSS_GENERIC(PIPE, false, true)                                                       \
     else                                                                                         \
-        hipLaunchKernelGGL((yh::loss_fwd_bwd_generic_kernel<PIPE, false>), grid,                 \
-                           dim3(yh::LOSS_THREADS), 0, st, pred, bias, gt_xywh, gt_cls, obj_mask, \
-                           grad_pred, rows_base, (long long)batch, S, Bx, C, g, cellf, imgf,     \
-                           lambda_coord, lambda_noobj, inv_global_batch, pp);
+        YH_LOSS_GENERIC(PIPE, false, false)
     if (pipe) { YH_LOSS_LAUNCH(true) } else { YH_LOSS_LAUNCH(false) }
 #undef YH_LOSS_LAUNCH
+#undef YH_LOSS_GENERIC
     return launch_status();
 }
 
