@@ -397,16 +397,19 @@ def test_pipelined_other_shape_and_errors(dev):
     torch.cuda.synchronize()
 
 
-def test_gradient_buffer_not_16_byte_aligned(dev):
-    """The benchmark-shape kernel stores its gradients in 16-byte units; a gradient
-    buffer that is only 4-byte aligned (legal by the header) takes the run-time-shape
-    kernel instead and must give the same result."""
+@pytest.mark.parametrize("S,Bx,C", [(7, 2, 20), (7, 3, 20), (13, 5, 20)])
+def test_gradient_buffer_not_16_byte_aligned(dev, S, Bx, C):
+    """The kernels that collect a workgroup's gradients in LDS store them in 16-byte
+    units; a gradient buffer that is only 4-byte aligned (legal by the header) takes
+    the kernel that stores directly and must give the same result.  For the run-time
+    shapes the two differ in the store path only: the same bits."""
     from yolo_amd import _lib
     lib = _lib.load()
     batch = 37
-    pred, gx, gc, om = (x.to(dev) for x in synth.make_inputs(batch, seed=77))
+    img = 32 * S
+    pred, gx, gc, om = (x.to(dev) for x in synth.make_inputs(batch, S, Bx, C, img, seed=77))
     om8 = om.view(torch.uint8)
-    ws = torch.empty(lib.yh_workspace_bytes(_lib.YH_OP_LOSS, batch, 7, 2, 20), dtype=torch.uint8, device=dev)
+    ws = torch.empty(lib.yh_workspace_bytes(_lib.YH_OP_LOSS, batch, S, Bx, C), dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     outs = []
     for shift in (0, 1, 2, 3):
@@ -415,13 +418,16 @@ def test_gradient_buffer_not_16_byte_aligned(dev):
         terms = torch.empty(5, device=dev)
         _lib.check(lib.yh_loss_fwd_bwd(pred.data_ptr(), gx.data_ptr(), gc.data_ptr(), om8.data_ptr(),
                                        grad.data_ptr(), terms.data_ptr(), ws.data_ptr(), ws.numel(),
-                                       batch, 7, 2, 20, 448, 5.0, 0.5, 1.0 / batch, st))
+                                       batch, S, Bx, C, img, 5.0, 0.5, 1.0 / batch, st))
         torch.cuda.synchronize()
         assert torch.isnan(buf[:shift]).all() and torch.isnan(buf[shift + pred.numel():]).all()
         outs.append((terms.clone(), grad.clone()))
-    ref = ref_cpu.loss_and_grad(pred.cpu(), gx.cpu(), gc.cpu(), om.cpu())
+    ref = ref_cpu.loss_and_grad(pred.cpu(), gx.cpu(), gc.cpu(), om.cpu(), n_cells=S, n_bboxes=Bx,
+                                n_classes=C, img_size=img)
     for terms, grad in outs:
         check_against_oracle(terms.cpu(), grad.cpu().view_as(ref["grad"]), ref)
     scale = outs[0][1].abs().max().item()
     for terms, grad in outs[1:]:
         assert (grad - outs[0][1]).abs().max().item() <= 1e-6 * scale
+        if (S, Bx, C) != (7, 2, 20):
+            assert torch.equal(grad, outs[0][1]) and torch.equal(terms, outs[0][0])
