@@ -141,6 +141,27 @@ def test_nms_tie_and_degenerate_cases(dev):
     assert_same(got, oracle_nms(ltrb, score, cls, present, 0.0, 0.5))
 
 
+def test_reference_mode_thresholds_and_ragged_batches(dev):
+    """Reference mode of the benchmark shape at thresholds that keep few, about half
+    and nearly all cells, over odd and even batch sizes (the last workgroup is then
+    partly empty), with and without a bias."""
+    head = YOLOv1Head()
+    for batch in (1, 2, 7, 8, 9, 33):
+        pred = synth.make_pred(batch, seed=100 + batch).to(dev)
+        ltrb, score, cls, present = head.decode_candidates(pred, MODE_REFERENCE)
+        for ct in (0.9, 0.5, 0.35, 0.05, 0.0):
+            got = head.postprocess(pred, ct, 0.4, MODE_REFERENCE, return_idx=True)
+            assert_same(got, oracle_nms(ltrb, score, cls, present, ct, 0.4))
+    bias = torch.randn(1470, device=dev)
+    pred = synth.make_pred(9, seed=5).to(dev)
+    z = pred - bias.view(1, 30, 7, 7)
+    for ct in (0.5, 0.05):
+        want = head.postprocess(z + bias.view(1, 30, 7, 7), ct, 0.5, MODE_REFERENCE, return_idx=True)
+        got = head.postprocess(z, ct, 0.5, MODE_REFERENCE, return_idx=True, bias=bias)
+        for g_, w_ in zip(got, want):
+            assert torch.equal(g_, w_)
+
+
 # ------------------------------------------------ fused kernel == NMS of its own candidates
 @pytest.mark.parametrize("S,Bx,C,batch,mode,ct,it", [
     (7, 2, 20, 16, MODE_REFERENCE, 0.5, 0.5),
