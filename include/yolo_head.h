@@ -43,6 +43,7 @@ extern "C" {
 #define YH_ERR_ALIGN (-4)       /* a pointer is not aligned as documented */
 #define YH_ERR_ARG (-5)         /* a scalar argument is invalid (mode, threshold is NaN, ...) */
 #define YH_ERR_UNSUPPORTED (-6) /* more candidates per image than the kernels handle */
+#define YH_ERR_SCRATCH (-7)     /* yh_loss_fwd_bwd_static: the batch does not fit the static scratch */
 
 /* limits checked on the host */
 #define YH_MAX_S 64
@@ -90,6 +91,27 @@ int yh_loss_fwd_bwd(const float* pred, const float* gt_xywh, const float* gt_cls
                     void* workspace, size_t workspace_bytes, int64_t batch, int S, int Bx,
                     int C, int img_size, float lambda_coord, float lambda_noobj,
                     float inv_global_batch, void* stream);
+
+/*
+ * yh_loss_fwd_bwd without a workspace argument and without any allocation.  It
+ * has no counterpart in the reference; it is for callers that cannot allocate
+ * device memory or pass a workspace: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  The loss rows (16 bytes per
+ * workgroup) go to an array of YH_STATIC_SCRATCH_BYTES that is part of the
+ * library image on every GPU the library runs on, for the life of the process;
+ * its device address is looked up once per device, on the first call made with
+ * that device current.  Same kernels and same bits as yh_loss_fwd_bwd.
+ * Limit: yh_workspace_bytes(YH_OP_LOSS, batch, S, Bx, C) <= YH_STATIC_SCRATCH_BYTES
+ * (batch <= 81,920 at S = 7; batch <= 16,384 for S >= 16), else YH_ERR_SCRATCH.
+ * All calls on one GPU share that GPU's array: calls that overlap there (two
+ * streams, two threads) race on the rows; order them.  Nothing in the array has
+ * to start at zero -- a call writes every row it later reads.
+ */
+#define YH_STATIC_SCRATCH_BYTES 262144
+int yh_loss_fwd_bwd_static(const float* pred, const float* gt_xywh, const float* gt_cls,
+                           const uint8_t* obj_mask, float* grad_pred, float* loss_terms,
+                           int64_t batch, int S, int Bx, int C, int img_size, float lambda_coord,
+                           float lambda_noobj, float inv_global_batch, void* stream);
 
 /*
  * The two halves of yh_loss_fwd_bwd as separate launches, for callers that put

@@ -35,7 +35,7 @@ def test_version_and_strerror():
     lib = _lib.load()
     assert lib.yh_version() == 100
     assert _lib.strerror(0) == "ok"
-    for rc in range(-6, 0):
+    for rc in range(-7, 0):
         assert _lib.strerror(rc).startswith("yolo_head:")
     assert "unknown" in _lib.strerror(-99)
 
@@ -43,7 +43,7 @@ def test_version_and_strerror():
 def test_constants_match_header():
     text = open(HEADER).read()
     for name in ("YH_ERR_NULL", "YH_ERR_SHAPE", "YH_ERR_WORKSPACE", "YH_ERR_ALIGN", "YH_ERR_ARG",
-                 "YH_ERR_UNSUPPORTED", "YH_OP_LOSS", "YH_MODE_REFERENCE", "YH_MODE_DENSE",
+                 "YH_ERR_UNSUPPORTED", "YH_ERR_SCRATCH", "YH_STATIC_SCRATCH_BYTES", "YH_OP_LOSS", "YH_MODE_REFERENCE", "YH_MODE_DENSE",
                  "YH_MAX_CANDIDATES"):
         m = re.search(rf"#define {name} \(?(-?\d+)\)?", text)
         assert m and int(m.group(1)) == getattr(_lib, name), name

@@ -24,6 +24,7 @@ YH_ERR_WORKSPACE = -3
 YH_ERR_ALIGN = -4
 YH_ERR_ARG = -5
 YH_ERR_UNSUPPORTED = -6
+YH_ERR_SCRATCH = -7
 
 YH_OP_LOSS = 0
 YH_OP_DECODE_NMS = 1
@@ -36,6 +37,7 @@ YH_MODE_REFERENCE = 0
 YH_MODE_DENSE = 1
 
 YH_MAX_CANDIDATES = 2048
+YH_STATIC_SCRATCH_BYTES = 262144
 
 YH_BOX_IOU = 0
 YH_BOX_GIOU = 1
@@ -49,6 +51,9 @@ SIGNATURES = {
     "yh_loss_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_int,
                                 c_float, c_float, c_float, c_void_p]),
+    "yh_loss_fwd_bwd_static": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int64, c_int, c_int, c_int, c_int, c_float, c_float,
+                                       c_float, c_void_p]),
     "yh_loss_partials": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_size_t, c_int64, c_int, c_int, c_int, c_int, c_float, c_float,
                                  c_float, c_void_p]),

@@ -7,6 +7,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "../../include/yolo_head.h"
 #include "decode_kernels.hpp"
 #include "loss_kernels.hpp"
@@ -14,6 +16,11 @@
 #include "target_kernels.hpp"
 #include "box_kernels.hpp"
 #include "map_kernels.hpp"
+
+// Loss rows of yh_loss_fwd_bwd_static: device memory that belongs to the library
+// image itself, one copy per GPU at that GPU's own address.  In host code the
+// name is only a handle for hipGetSymbolAddress, never a device address.
+static __device__ __align__(256) float scratch[YH_STATIC_SCRATCH_BYTES / sizeof(float)];
 
 namespace {
 
@@ -146,6 +153,9 @@ const char* yh_strerror(int rc) {
         case YH_ERR_ALIGN: return "yolo_head: pointer not aligned as documented";
         case YH_ERR_ARG: return "yolo_head: invalid scalar argument";
         case YH_ERR_UNSUPPORTED: return "yolo_head: more than 2048 candidates per image";
+        case YH_ERR_SCRATCH:
+            return "yolo_head: the batch needs more loss rows than the static scratch array holds "
+                   "(or its device address could not be resolved)";
         default: break;
     }
     if (rc > 0) return hipGetErrorString((hipError_t)rc);
@@ -326,6 +336,49 @@ int yh_loss_finalize(const void* workspace, size_t workspace_bytes, int64_t batc
                        (const float*)workspace, (int)loss_blocks(batch, S), inv_global_batch,
                        loss_terms, log_ring, log_capacity, (int*)log_cursor);
     return launch_status();
+}
+
+// Device address of `scratch` on the current device, resolved once per device
+// (with that device current) and kept; nullptr with *err set on failure.
+static float* static_scratch_ptr(int* err) {
+    constexpr int kMaxDevices = 64;
+    static std::atomic<float*> ptrs[kMaxDevices];
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { *err = (int)e; return nullptr; }
+    if (dev < 0 || dev >= kMaxDevices) { *err = YH_ERR_SCRATCH; return nullptr; }
+    float* p = ptrs[dev].load(std::memory_order_acquire);
+    if (!p) {
+        // two threads may both get here: they resolve the same address
+        void* sym = nullptr;
+        e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !sym) { *err = e != hipSuccess ? (int)e : YH_ERR_SCRATCH; return nullptr; }
+        p = (float*)sym;
+        ptrs[dev].store(p, std::memory_order_release);
+    }
+    return p;
+}
+
+int yh_loss_fwd_bwd_static(const float* pred, const float* gt_xywh, const float* gt_cls,
+                           const uint8_t* obj_mask, float* grad_pred, float* loss_terms,
+                           int64_t batch, int S, int Bx, int C, int img_size, float lambda_coord,
+                           float lambda_noobj, float inv_global_batch, void* stream) {
+    if (const int rc = check_shape(batch, S, Bx, C, img_size)) return rc;
+    if (!loss_terms) return YH_ERR_NULL;
+    // one row of 16 bytes per workgroup must fit the static array
+    if (yh_workspace_bytes(YH_OP_LOSS, batch, S, Bx, C) > (size_t)YH_STATIC_SCRATCH_BYTES)
+        return YH_ERR_SCRATCH;
+    int err = YH_OK;
+    float* rows = static_scratch_ptr(&err);
+    if (!rows) return err;
+    // every row the finalize kernel reads is written by this call's first kernel:
+    // nothing in the array has to start at zero
+    if (const int rc = loss_launch(pred, nullptr, gt_xywh, gt_cls, obj_mask, grad_pred, rows, batch,
+                                   S, Bx, C, img_size, lambda_coord, lambda_noobj,
+                                   inv_global_batch, nullptr, (hipStream_t)stream))
+        return rc;
+    return yh_loss_finalize(rows, YH_STATIC_SCRATCH_BYTES, batch, S, inv_global_batch, loss_terms,
+                            nullptr, 0, nullptr, stream);
 }
 
 int yh_loss_fwd_bwd(const float* pred, const float* gt_xywh, const float* gt_cls,
