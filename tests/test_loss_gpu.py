@@ -3,7 +3,10 @@ the C ABI.  Tolerance: the target is 1e-5 relative in fp32.  Scalars (the three
 term sums, the total, the loss) are compared at rtol 1e-5.  The gradient is
 compared with max|hip - oracle| <= 1e-5 * max|oracle| -- relative to the
 tensor's scale, because single elements are differences of nearly equal terms
-(conf - IoU) whose own fp32 rounding in the oracle is already ~1e-7 absolute."""
+(conf - IoU) whose own fp32 rounding in the oracle is already ~1e-7 absolute;
+test_gradient_per_channel_group_and_element_by_element applies the same bound to
+every channel group against its own scale and compares element by element with
+what PyTorch's fp32 autograd itself achieves against fp64."""
 import numpy as np
 import pytest
 import torch
@@ -54,6 +57,100 @@ def test_config1_matches_oracle_and_golden(dev, golden):
     assert abs(terms[1].item() - float(t6["conf"])) <= RTOL * float(t6["conf"])
     assert abs(terms[2].item() - float(t6["cls"])) <= RTOL * float(t6["cls"])
     assert abs(terms[4].item() - float(t6["loss"])) <= RTOL * float(t6["loss"])
+
+
+# Channel groups of the head tensor (model.py:140-142) at Bx=2, C=20, each with its own
+# gradient scale: the box centre, the box size, the confidences, the classes.
+GROUPS = {"xy": [0, 1, 5, 6], "wh": [2, 3, 7, 8], "conf": [4, 9], "cls": list(range(10, 30))}
+
+
+def test_gradient_per_channel_group_and_element_by_element(dev):
+    """The gradient at the stated tolerance, group by group and element by element,
+    against the fp64 oracle, with the fp32 oracle (PyTorch CPU autograd) as the
+    yardstick for what fp32 arithmetic can deliver.
+
+    (i) max-norm per channel group and per kind of cell (object / no object), each
+    against that group's own largest gradient: <= 1e-5.  A group-blind max-norm
+    would let the small no-object confidence gradients hide behind the box ones.
+    (ii) element by element over the entries above 1e-3 of the group's scale.  Single
+    entries are differences of nearly equal terms (conf - IoU, conf * (1 - conf) near
+    saturation, the left and right edge terms of the IoU gradient), so PyTorch's own
+    fp32 result is up to 4e-4 away from fp64 on some of them; 1e-5 on every entry is
+    not a property fp32 has.  What is asserted: the kernel is no further from fp64
+    than PyTorch fp32 is -- largest and median relative error at most 2x (1.5x) the
+    fp32 oracle's, and no more entries beyond 1e-5 than 1.5x the fp32 oracle's count
+    (+ 0.05 % of the entries)."""
+    batch = 1024
+    head = YOLOv1Head()
+    pred, gx, gc, om = synth.make_inputs(batch, seed=0)
+    _, grad = run_hip(head, dev, pred, gx, gc, om)
+    grad = grad.double()
+    g32 = ref_cpu.loss_and_grad(pred, gx, gc, om)["grad"].double()
+    g64 = ref_cpu.loss_and_grad(pred, gx, gc, om, dtype=torch.float64)["grad"]
+    obj = om[:, :, 0, 0].view(batch, 1, 7, 7).expand(batch, 30, 7, 7)
+    checked = 0
+    for name, chans in GROUPS.items():
+        for part, mask in (("obj", obj[:, chans]), ("noobj", ~obj[:, chans])):
+            a, b, r = grad[:, chans][mask], g32[:, chans][mask], g64[:, chans][mask]
+            scale = r.abs().max().item()
+            if scale == 0.0:
+                assert a.abs().max().item() == 0.0, (name, part)   # exact zeros stay exact zeros
+                continue
+            eh, eo = (a - r).abs(), (b - r).abs()
+            assert eh.max().item() <= RTOL * scale, (name, part, eh.max().item(), scale)
+            big = r.abs() > 1e-3 * scale
+            rh, ro = eh[big] / r.abs()[big], eo[big] / r.abs()[big]
+            assert rh.max().item() <= max(2.0 * ro.max().item(), RTOL), (name, part, rh.max(), ro.max())
+            assert rh.median().item() <= max(1.5 * ro.median().item(), 1e-7), (name, part)
+            over_h, over_o = int((rh > RTOL).sum()), int((ro > RTOL).sum())
+            assert over_h <= 1.5 * over_o + 5e-4 * rh.numel(), (name, part, over_h, over_o)
+            checked += 1
+    assert checked == 5      # xy, wh, cls of object cells; conf of both kinds
+
+
+def test_logits_beyond_the_exponential_range(dev):
+    """Logits at +-89, +-100 and +-1e4: exp(-x) overflows fp32 there.  torch.sigmoid
+    returns 0 or 1 (to within a denormal); the kernels must do the same instead of
+    turning inf * 0 into NaN -- in the loss, the grid decode and decode + NMS."""
+    from yolo_amd import MODE_DENSE, MODE_REFERENCE
+    head = YOLOv1Head()
+    pred, gx, gc, om = synth.make_inputs(12, seed=91)
+    vals = torch.tensor([89.0, -89.0, 100.0, -100.0, 1e4, -1e4, 88.7, -88.8, 3e38, -3e38])
+    g = torch.Generator().manual_seed(4)
+    for b in range(10):
+        hit = torch.rand(30, 7, 7, generator=g) < 0.3
+        pred[b][hit] = vals[b]
+    pred[10] = vals[torch.randint(0, 10, (30, 7, 7), generator=g)]     # nothing but extremes
+    # every channel of a cell at the same huge value: softmax of equal logits
+    pred[11, :, 3, 3] = 1e4
+    terms, grad = run_hip(head, dev, pred, gx, gc, om)
+    assert torch.isfinite(terms).all() and torch.isfinite(grad).all()
+    ref = ref_cpu.loss_and_grad(pred, gx, gc, om)
+    bad = ~torch.isfinite(ref["grad"])      # 0 * NaN of the masked IoU backward (see the test above)
+    assert (grad[bad] == 0).all()
+    ref["grad"] = torch.where(bad, torch.zeros_like(ref["grad"]), ref["grad"])
+    check_against_oracle(terms, grad, ref)
+
+    d = pred.to(dev)
+    conf = head.get_confidence(d).cpu()
+    assert torch.isfinite(conf).all()
+    torch.testing.assert_close(conf, ref_cpu.get_confidence(pred, 2), rtol=0, atol=1e-6)
+    ltrb = head.get_ltrb(d).cpu()
+    assert torch.isfinite(ltrb).all()
+    torch.testing.assert_close(ltrb, ref_cpu.get_ltrb(pred, 7, 2, 448), rtol=1e-5, atol=2e-4)
+    prob = head.get_classification_prob(d).cpu()
+    assert torch.isfinite(prob).all()
+    torch.testing.assert_close(prob, ref_cpu.get_classification_prob(pred, 2, 20), rtol=1e-5, atol=1e-7)
+    for mode in (MODE_REFERENCE, MODE_DENSE):
+        dets, count, kidx = head.postprocess(d, 0.25, 0.5, mode, return_idx=True)
+        cl, cs, cc, cp = head.decode_candidates(d, mode)
+        assert torch.isfinite(cl).all() and torch.isfinite(cs).all()
+        torch.testing.assert_close(cs.view(12, 49, 2, 1).cpu(), ref_cpu.get_confidence(pred, 2), rtol=0, atol=1e-6)
+        wd, wc, wk = ref_cpu.nms_batch(cl.cpu().numpy(), cs.cpu().numpy(), cc.cpu().numpy(),
+                                       cp.cpu().numpy(), 0.25, 0.5)
+        assert np.array_equal(count.cpu().numpy(), wc) and np.array_equal(kidx.cpu().numpy(), wk)
+        assert np.array_equal(dets.cpu().numpy().view(np.uint32), wd.view(np.uint32))
+        assert int(count.sum()) > 0
 
 
 def test_fp64_oracle_agrees(dev):

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void responsibility_mask_kernel(
                 const Box b = decode_box(sigmoidf_(p[(5 * k) * S2]), sigmoidf_(p[(5 * k + 1) * S2]),
                                          sigmoidf_(p[(5 * k + 2) * S2]),
                                          sigmoidf_(p[(5 * k + 3) * S2]), xoff, yoff, cellf, imgf);
-                const float iou = iou_pair_fast(b, gbox);
+                const float iou = iou_pair(b, gbox);
                 if (k == 0 || iou > biou) { best = k; biou = iou; }
             }
         }

@@ -15,14 +15,34 @@ struct Box {
     float l, t, r, b;
 };
 
+// v_max_f32 / v_min_f32 on values as they are: fmaxf/fminf would first quiet a
+// signalling NaN in each operand (one more instruction per operand)
+__device__ __forceinline__ float vmax_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmin_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // exp(x) on the hardware base-2 exponential (v_exp_f32, 1 ulp).  The product
 // x*log2(e) is split with a fused multiply-add so that neither its rounding nor
-// the rounding of the constant reaches the result: about 2 ulp for every
-// finite x, at 6 instructions instead of the ~15 of a correctly rounded expf.
-__device__ __forceinline__ float exp_fast(float x) {
+// the rounding of the constant reaches the result: about 2 ulp on [-87, 88.72],
+// at 7 instructions instead of the ~15 of a correctly rounded expf.  The
+// argument is held inside [-104, 88.72] (one v_med3_f32): above, v_exp_f32
+// returns +inf and inf * r + inf is NaN whenever the residual r is negative;
+// far below, x*log2(e) itself overflows and r becomes inf - inf.  exp(-104)
+// is below the smallest denormal and exp(88.72) = 3.39e38 is finite; the
+// callers form 1 / (1 + exp) or exp of a value <= 0, so the plateaus cost less
+// than 3e-39 absolute.
+__device__ __forceinline__ float exp_fast(float x_in) {
     constexpr float kLog2e = 1.44269502162933349609375f;   // fp32(log2 e)
     constexpr float kLog2eLo = 1.925963033500011e-08f;      // log2 e - kLog2e
     constexpr float kLn2 = 0.693147182464599609375f;
+    const float x = __builtin_amdgcn_fmed3f(x_in, -104.0f, 88.72f);
     const float t = x * kLog2e;
     const float r = __builtin_fmaf(x, kLog2e, -t) + x * kLog2eLo;   // what t lost
     const float e = __builtin_amdgcn_exp2f(t);
@@ -104,19 +124,6 @@ inline IouGate make_iou_gate(float thr) {
     return g;
 }
 
-// v_max_f32 / v_min_f32 on values as they are: fmaxf/fminf would first quiet a
-// signalling NaN in each operand (one more instruction per operand)
-__device__ __forceinline__ float vmax_raw(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float vmin_raw(float a, float b) {
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 __device__ __forceinline__ bool iou_above(const Box& p, const Box& g, const IouGate& gate) {
     const float a1 = box_area(p);
     const float a2 = box_area(g);
@@ -127,18 +134,6 @@ __device__ __forceinline__ bool iou_above(const Box& p, const Box& g, const IouG
     if (gate.mode == 0) return (uni == 0.0f ? 0.0f : inter / uni) > gate.thr;
     const double lhs = (double)inter, rhs = gate.mid * (double)uni;
     return uni != 0.0f && (gate.mode == 1 ? lhs > rhs : lhs >= rhs);
-}
-
-// iou_pair with the quotient formed as inter * (1/uni) on v_rcp_f32 (<= 2 ulp):
-// for the loss, where the value is compared at a tolerance, not bit for bit.
-__device__ __forceinline__ float iou_pair_fast(const Box& p, const Box& g) {
-    const float a1 = box_area(p);
-    const float a2 = box_area(g);
-    const float iw = fmaxf(fminf(p.r, g.r) - fmaxf(p.l, g.l), 0.0f);
-    const float ih = fmaxf(fminf(p.b, g.b) - fmaxf(p.t, g.t), 0.0f);
-    const float inter = iw * ih;
-    const float uni = (a1 + a2) - inter;
-    return uni == 0.0f ? 0.0f : inter * rcp_fast(uni);
 }
 
 // share of the gradient that max(a, b) (or min) sends to a: all of it when a

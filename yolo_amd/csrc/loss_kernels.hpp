@@ -125,7 +125,7 @@ __device__ __forceinline__ void loss_obj_cell(const L& logit, float* __restrict_
         const float ny = sigmoidf_(logit(5 * k + 1));
         const float nw = sigmoidf_(logit(5 * k + 2));
         const float nh = sigmoidf_(logit(5 * k + 3));
-        const float iou = iou_pair_fast(decode_box(nx, ny, nw, nh, xoff, yoff, cellf, imgf), gbox);
+        const float iou = iou_pair(decode_box(nx, ny, nw, nh, xoff, yoff, cellf, imgf), gbox);
         if (k == 0 || iou > biou) {
             best = k; biou = iou; bnx = nx; bny = ny; bnw = nw; bnh = nh;
         }
@@ -267,7 +267,7 @@ __device__ __forceinline__ void loss_obj_cell_wave(
         nw = sigmoidf_(l2);
         nh = sigmoidf_(l3);
         conf = sigmoidf_(l4);
-        iou = iou_pair_fast(decode_box(nx, ny, nw, nh, xoff, yoff, cellf, imgf), gbox);
+        iou = iou_pair(decode_box(nx, ny, nw, nh, xoff, yoff, cellf, imgf), gbox);
     }
     // responsible predictor: highest IoU, first index on ties (model.py:210) -- the
     // one-lane rule, applied to the lanes' values in predictor order
