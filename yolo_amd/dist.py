@@ -64,6 +64,22 @@ class LossAllReducer:
                 work = dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append((work, rows))
 
+    def flush_rows(self, rows: torch.Tensor) -> None:
+        """As ``flush`` for a ring that holds every step of the run: ``rows`` (a view of
+        the steps just logged) is all-reduced in place, no copy is made, and the view
+        is kept for ``results()``; the caller must not let the ring wrap onto it."""
+        if rows.shape[0] == 0:
+            return
+        work = None
+        if self.world_size > 1:
+            if rows.is_cuda and dist.get_backend(self.group) == "gloo":
+                host = rows.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                rows.copy_(host)
+            else:
+                work = dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append((work, rows))
+
     def results(self) -> torch.Tensor:
         out = []
         for work, rows in self._pending:
@@ -73,4 +89,4 @@ class LossAllReducer:
         self._pending = [(None, r) for r in out]
         if not out:
             return torch.zeros(0, 4)
-        return torch.cat(out, dim=0)
+        return out[0] if len(out) == 1 else torch.cat(out, dim=0)
