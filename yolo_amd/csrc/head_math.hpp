@@ -28,6 +28,22 @@ __device__ __forceinline__ float vmin_raw(float a, float b) {
     return r;
 }
 
+// Streaming (non-temporal) stores for outputs that no workgroup reads again: the
+// lines leave the L2 as they fill instead of waiting there for the write-back at
+// the end of the kernel, which otherwise sits between two kernels of a stream
+// (24 MB of gradients per launch at batch 4096).  Worth it only where a wavefront
+// instruction covers whole 128-byte lines; partial lines cost a read-modify-write.
+typedef float yh_v4f __attribute__((ext_vector_type(4)));
+typedef float yh_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_stream(float4* dst, const float4& q) {
+    const yh_v4f v = {q.x, q.y, q.z, q.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<yh_v4f*>(dst));
+}
+__device__ __forceinline__ void store_stream(float2* dst, const float2& q) {
+    const yh_v2f v = {q.x, q.y};
+    __builtin_nontemporal_store(v, reinterpret_cast<yh_v2f*>(dst));
+}
+
 // exp(x) on the hardware base-2 exponential (v_exp_f32, 1 ulp).  The product
 // x*log2(e) is split with a fused multiply-add so that neither its rounding nor
 // the rounding of the constant reaches the result: about 2 ulp on [-87, 88.72],

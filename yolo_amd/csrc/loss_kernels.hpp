@@ -20,6 +20,7 @@ namespace yh {
 
 constexpr int LOSS_THREADS = 256;
 
+
 // A cell without object: only the no-object confidence term (model.py:270-274);
 // every other gradient of the cell is zero.  `logit(ch)` returns channel ch of
 // the cell, `g` points at the cell's gradient (channels S2 floats apart).
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
         const int n4 = n > head ? (n - head) >> 2 : 0;
         const float4* s4 = reinterpret_cast<const float4*>(gtile + pad + head);
         float4* g4 = reinterpret_cast<float4*>(gout + head);
-        for (int i = threadIdx.x; i < n4; i += LOSS_THREADS) g4[i] = s4[i];
+        for (int i = threadIdx.x; i < n4; i += LOSS_THREADS) store_stream(g4 + i, s4[i]);
         const int done = head + 4 * n4;
         if ((int)threadIdx.x < n - done) gout[done + threadIdx.x] = gtile[pad + done + threadIdx.x];
     }
@@ -721,6 +722,13 @@ __device__ __forceinline__ void loss_block(
         const long long img = img0 + gi;
         if (item < nitems && img < batch) {
             const long long tcell = img * S2 + cell;
+            // every cell needs its confidence logits: requested together with the mask
+            float vc[BX];
+            {
+                const float* p = pred + img * (long long)D * S2 + cell;
+#pragma unroll
+                for (int k = 0; k < BX; ++k) vc[k] = p[(5 * k + 4) * S2];
+            }
             has_obj = obj_mask[tcell] != 0;
             if (has_obj) {
                 // the cell's logits are requested now and wait for pass 2 in the very tile
@@ -729,7 +737,10 @@ __device__ __forceinline__ void loss_block(
                 const float* p = pred + img * (long long)D * S2 + cell;
                 float v[D];
 #pragma unroll
-                for (int ch = 0; ch < D; ++ch) v[ch] = p[ch * S2];
+                for (int ch = 0; ch < D; ++ch) {
+                    if (ch < 5 * BX && ch % 5 == 4) v[ch] = vc[ch / 5];
+                    else v[ch] = p[ch * S2];
+                }
                 if constexpr (BIAS) {
                     const float* bq = bias + cell;
 #pragma unroll
@@ -739,10 +750,6 @@ __device__ __forceinline__ void loss_block(
 #pragma unroll
                 for (int ch = 0; ch < D; ++ch) gl[ch * S2] = v[ch];
             } else {
-                const float* p = pred + img * (long long)D * S2 + cell;
-                float vc[BX];
-#pragma unroll
-                for (int k = 0; k < BX; ++k) vc[k] = p[(5 * k + 4) * S2];
                 if constexpr (BIAS) {
 #pragma unroll
                     for (int k = 0; k < BX; ++k) vc[k] += bias[(5 * k + 4) * S2 + cell];
@@ -802,7 +809,7 @@ __device__ __forceinline__ void loss_block(
         const int n4 = n > head ? (n - head) >> 2 : 0;
         const float4* s4 = reinterpret_cast<const float4*>(sgrad + pad + head);
         float4* g4 = reinterpret_cast<float4*>(gout + head);
-        for (int i = threadIdx.x; i < n4; i += LOSS_THREADS) g4[i] = s4[i];
+        for (int i = threadIdx.x; i < n4; i += LOSS_THREADS) store_stream(g4 + i, s4[i]);
         const int done = head + 4 * n4;
         if ((int)threadIdx.x < n - done) gout[done + threadIdx.x] = sgrad[pad + done + threadIdx.x];
     }

@@ -705,13 +705,13 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
     for (int e = 0; e < ITEMS; ++e) {
         if (al[e]) {
             float2* row = dst2 + pos_out[e] * 3;
-            row[0] = make_float2(mybox[e].l, mybox[e].t);
-            row[1] = make_float2(mybox[e].r, mybox[e].b);
-            row[2] = make_float2(__int_as_float(mymeta[e].x), (float)mymeta[e].y);
+            store_stream(row + 0, make_float2(mybox[e].l, mybox[e].t));
+            store_stream(row + 1, make_float2(mybox[e].r, mybox[e].b));
+            store_stream(row + 2, make_float2(__int_as_float(mymeta[e].x), (float)mymeta[e].y));
             if (kd) kd[pos_out[e]] = mymeta[e].z;
         }
     }
-    for (int i = total * 3 + t; i < nout * 3; i += NT) dst2[i] = make_float2(0.0f, 0.0f);
+    for (int i = total * 3 + t; i < nout * 3; i += NT) store_stream(dst2 + i, make_float2(0.0f, 0.0f));
     if (kd)
         for (int i = total + t; i < nout; i += NT) kd[i] = -1;
     if (t == 0) a.keep_count[img] = total;
