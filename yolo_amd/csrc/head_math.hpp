@@ -152,6 +152,39 @@ __device__ __forceinline__ bool iou_above(const Box& p, const Box& g, const IouG
     return uni != 0.0f && (gate.mode == 1 ? lhs > rhs : lhs >= rhs);
 }
 
+// "iou_pair(p, g) > thr" for a wavefront: the quotient formed with v_rcp_f32 is
+// within 3e-7 relative of the correctly rounded one, so outside the band
+// [lo, hi] = thr * (1 -+ 2e-6) it decides; a lane inside the band (or with a
+// NaN from 0 * inf) takes the IEEE division, and the wavefront skips that code
+// unless one of its lanes needs it.  thr <= 0 or not finite: lo = -inf,
+// hi = +inf, every lane divides.  Same answer as iou_pair(...) > thr, always.
+struct IouBand {
+    float thr, lo, hi;
+};
+__device__ __forceinline__ IouBand make_iou_band(float thr) {
+    IouBand b = {thr, -INFINITY, INFINITY};
+    if (thr > 0.0f && thr < 1e30f) {
+        b.lo = thr * (1.0f - 2e-6f);
+        b.hi = thr * (1.0f + 2e-6f);
+    }
+    return b;
+}
+__device__ __forceinline__ bool iou_above_band(const Box& p, const Box& g, const IouBand& band) {
+    const float a1 = box_area(p);
+    const float a2 = box_area(g);
+    const float iw = fmaxf(vmin_raw(p.r, g.r) - vmax_raw(p.l, g.l), 0.0f);
+    const float ih = fmaxf(vmin_raw(p.b, g.b) - vmax_raw(p.t, g.t), 0.0f);
+    const float inter = iw * ih;
+    const float uni = (a1 + a2) - inter;
+    const float q = inter * rcp_fast(uni);
+    bool above = q > band.hi;
+    const bool unsure = !(q > band.hi) && !(q < band.lo);
+    if (__ballot(unsure)) {
+        if (unsure) above = (uni == 0.0f ? 0.0f : inter / uni) > band.thr;
+    }
+    return above;
+}
+
 // share of the gradient that max(a, b) (or min) sends to a: all of it when a
 // wins, half on an exact tie (torch.maximum / torch.minimum backward).
 __device__ __forceinline__ float pick_max(float a, float b) {
@@ -227,6 +260,19 @@ __device__ __forceinline__ float row16_maxf(float v) {
     v = fmaxf(v, dpp_row<0x141>(v));
     v = fmaxf(v, dpp_row<0x140>(v));
     return v;
+}
+// Exclusive prefix sum over the 64 lanes on the DPP path: a shifted-add scan
+// inside each row of 16, then lane 15 of rows 0 and 2 into rows 1 and 3
+// (row_bcast:15), then lane 31 into rows 2 and 3 (row_bcast:31).  All lanes active.
+__device__ __forceinline__ int wave_excl_scan(int v) {
+    int x = v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+    return x - v;
 }
 __device__ __forceinline__ float wave_sum(float v) {
     v = row16_sum(v);

@@ -49,7 +49,7 @@ struct NmsArgs {
     float cellf, imgf, conf_thr, iou_thr;
     IouGate gate;   // iou_thr, prepared for the division-free comparison
     // per-image LDS region: byte offsets of the arrays inside it, and its size
-    int off_keys, off_box, off_meta, off_seg, off_alive, off_misc, off_ccls, off_hist, off_segst, off_pair;
+    int off_keys, off_box, off_meta, off_seg, off_alive, off_misc, off_ccls, off_hist, off_segst, off_pair, off_kill;
     int region_bytes;
     int dbg_stop;  // builds with -DYH_PHASE_PROBE only: leave after this phase (0 = run everything)
 };
@@ -221,6 +221,15 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                         }
                         auto logit = [&](int ch) -> float { return v[ch]; };
                         k = cell_best_conf(logit, BX_CT, cb);
+                        // The box logits of EVERY predictor are wanted in registers here.
+                        // Without this the compiler turns "select among loaded values" into
+                        // "load from a selected address", and the four loads of the chosen
+                        // box become a second, dependent trip to memory behind the
+                        // confidence compare.
+#pragma unroll
+                        for (int q = 0; q < BX_CT; ++q)
+                            asm volatile("" : "+v"(v[5 * q]), "+v"(v[5 * q + 1]), "+v"(v[5 * q + 2]),
+                                              "+v"(v[5 * q + 3]));
                         float lx = v[0], ly = v[1], lw = v[2], lh = v[3];
 #pragma unroll
                         for (int q = 1; q < BX_CT; ++q)
@@ -299,6 +308,95 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
 #ifdef YH_PHASE_PROBE
     if (a.dbg_stop == 1) { if (cvalid[0] && cscore[0] == 12345.f) a.keep_count[img] = ccl[0] + (int)cbox[0].l; return; }
 #endif
+    // One wavefront per image, one candidate per lane, classes that fit a 64-entry
+    // table: no sort.  The lanes of a class find each other through a class -> lane
+    // mask table in LDS (one 64-bit OR per lane).  Every pair of a class is then
+    // looked at once, the pairs of a class of n spread evenly over its members: a
+    // member takes the (n-1)/2 members that follow it cyclically in lane order (one
+    // more for the first half of an even class), so the loop runs about half as
+    // long as the largest class.  For a pair, the member that comes later in the
+    // output order (lower score, higher index on equal scores) gets the other one's
+    // bit in its `higher` word and, when their IoU exceeds the threshold, in its
+    // `killers` word (LDS ORs).  Greedy NMS is the fixed point "kept iff no killer
+    // is kept", reached in as many ballot rounds as the longest chain.  The output
+    // row is the number of kept lanes of lower classes (per-class counts from the
+    // mask table, prefix-summed across lanes) plus the kept lanes in `higher`.
+    if constexpr (kWave && ITEMS == 1 && kHead) {
+        const int nc_tab = C_CT > 0 ? C_CT : a.nc;
+        if (nc_tab <= 64) {
+            unsigned long long* killt = reinterpret_cast<unsigned long long*>(region + a.off_kill);
+            unsigned long long* hight = killt + 64;
+            float* sscore = reinterpret_cast<float*>(smeta);
+            const unsigned long long me = 1ull << lane;
+            const bool valid = cvalid[0];
+            const float myscore = cscore[0];
+            keys[lane] = 0ull;
+            killt[lane] = 0ull;
+            hight[lane] = 0ull;
+            sbox[lane] = make_float4(cbox[0].l, cbox[0].t, cbox[0].r, cbox[0].b);
+            sscore[lane] = myscore;
+            group_sync<NT>();
+            if (valid) atomicOr(&keys[ccl[0]], me);
+            group_sync<NT>();
+            const unsigned long long mine = valid ? keys[ccl[0]] : 0ull;
+            const int n = __popcll(mine);
+            const int p = __popcll(mine & (me - 1ull));
+            int h = (n - 1) >> 1;                       // -1 for a lane without a candidate
+            if (n > 0 && (n & 1) == 0 && p < (n >> 1)) ++h;
+            // bit k of `rot` is lane (lane + 1 + k) & 63: the members after this one, cyclically
+            const int sh = (lane + 1) & 63;
+            unsigned long long rot = sh ? (mine >> sh) | (mine << (64 - sh)) : mine;
+            const IouBand band = make_iou_band(a.iou_thr);
+            while (__ballot(h > 0)) {
+                if (h > 0) {
+                    --h;
+                    const int j = (lane + __ffsll((long long)rot)) & 63;    // ffs = k + 1
+                    rot &= rot - 1ull;
+                    const float sj = sscore[j];
+                    const float4 b = sbox[j];
+                    const bool j_first = sj > myscore || (sj == myscore && j < lane);
+                    const int later = j_first ? lane : j;
+                    const unsigned long long first_bit = 1ull << (j_first ? j : lane);
+                    atomicOr(&hight[later], first_bit);
+                    if (iou_above_band({b.x, b.y, b.z, b.w}, cbox[0], band)) atomicOr(&killt[later], first_bit);
+                }
+            }
+            group_sync<NT>();
+            const unsigned long long killers = killt[lane], higher = hight[lane];
+            unsigned long long undec = __ballot(valid), kept = 0ull;
+            while (undec) {
+                const bool und = (undec >> lane) & 1ull;
+                const bool die = und && (killers & kept) != 0ull;
+                const bool keep = und && !die && (killers & undec) == 0ull;
+                const unsigned long long km = __ballot(keep);
+                kept |= km;
+                undec &= ~(km | __ballot(die));
+            }
+            // kept lanes per class -> first output row of each class
+            int* cbase = sseg;
+            cbase[lane] = wave_excl_scan(lane < nc_tab ? __popcll(keys[lane] & kept) : 0);
+            group_sync<NT>();
+            const bool iskept = (kept >> lane) & 1ull;
+            const int pos = iskept ? cbase[ccl[0]] + __popcll(higher & kept) : 0;
+            const int total = __popcll(kept);
+            const int nout = a.nout;
+            float2* dst2 = reinterpret_cast<float2*>(a.dets + img * (long long)nout * 6);
+            int32_t* kd = a.keep_idx ? a.keep_idx + img * (long long)nout : nullptr;
+            if (iskept) {
+                float2* row = dst2 + pos * 3;
+                store_stream(row + 0, make_float2(cbox[0].l, cbox[0].t));
+                store_stream(row + 1, make_float2(cbox[0].r, cbox[0].b));
+                store_stream(row + 2, make_float2(cscore[0], (float)ccl[0]));
+                if (kd) kd[pos] = cidx[0];
+            }
+            for (int i = total * 3 + t; i < nout * 3; i += NT) store_stream(dst2 + i, make_float2(0.0f, 0.0f));
+            if (kd)
+                for (int i = total + t; i < nout; i += NT) kd[i] = -1;
+            if (t == 0) a.keep_count[img] = total;
+            return;
+        }
+    }
+
     // ---- phase B: keys, rank, segment start ---------------------------------------
     unsigned long long key[ITEMS], clsbase[ITEMS];
 #pragma unroll

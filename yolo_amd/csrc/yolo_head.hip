@@ -82,6 +82,9 @@ void nms_layout(yh::NmsArgs& a, int slot_pad) {
     // pair offsets per position (a workgroup per image): slot_pad + 1 ints in the place of
     // the 2 * slot_pad ints at off_meta, which are dead by then
     a.off_pair = a.off_meta;
+    // kill and precedence tables of the one-wavefront path: 2 x 64 words of 64 bits
+    a.off_kill = off;
+    off += 1024;
     a.region_bytes = off;
 }
 
