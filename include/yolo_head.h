@@ -228,10 +228,15 @@ int yh_box_area(const float* ltrb, float* out, int64_t n, void* stream);
  * (eval.py:125).  Predictions are ranked by confidence descending, equal
  * confidences by lower index (torch.argsort leaves ties unspecified).
  *   pred (P, 6) rows l,t,r,b,conf,class (the rows yh_decode_nms writes);
- *   gt (G, 5) rows l,t,r,b,class; P <= 16384.
+ *   gt (G, 5) rows l,t,r,b,class; P, G <= YH_MAP_MAX_ROWS (a whole dataset's
+ *   detections in one call, as eval.get_map takes them).  A NaN confidence ranks last.
  *   ap_out (n_classes) float64, map_out (1) float64 (eval.py:142, :149).
- *   workspace: yh_workspace_bytes(YH_OP_MAP, P, 0, 0, 0) bytes.
+ *   workspace: yh_map_workspace_bytes(P, G) bytes, 256-byte aligned: sort keys and
+ *   the temporary storage of the device radix sort.  The call queries the device
+ *   (occupancy) on the host: keep it out of graph capture.
  */
+#define YH_MAP_MAX_ROWS 16777216
+size_t yh_map_workspace_bytes(int64_t P, int64_t G);
 int yh_map_11point(const float* pred, const float* gt, int64_t P, int64_t G, int n_classes,
                    float iou_thresh, double* ap_out, double* map_out, void* workspace,
                    size_t workspace_bytes, void* stream);

@@ -67,5 +67,59 @@ def test_gpu_map_edge_cases_and_pipeline(dev):
                                 torch.randint(0, 20, (P, 1), generator=gen).float())], dim=1)
     pl[10, 4] = pl[20, 4]                                        # a confidence tie
     assert box_ops.get_map(pl.to(dev), gtl.to(dev), 20, 4.0).item() == ref_cpu.get_map(pl, gtl, 20, 4.0)
-    with pytest.raises(Exception):
-        box_ops.get_map(torch.zeros(20000, 6, device=dev), gtl.to(dev), 20)
+    # a NaN confidence ranks last (after every number, NaNs among themselves by row)
+    pn = pl.clone()
+    pn[5, 4] = float("nan")
+    pn[77, 4] = float("nan")
+    assert box_ops.get_map(pn.to(dev), gtl.to(dev), 20, 4.0).item() == ref_cpu.get_map(pn, gtl, 20, 4.0)
+
+
+def _random_problem(P, G, ncls, seed):
+    gen = torch.Generator().manual_seed(seed)
+    gb = torch.rand(G, 2, generator=gen) * 400
+    gtl = torch.cat([gb, gb + 10 + torch.rand(G, 2, generator=gen) * 40,
+                     torch.randint(0, ncls, (G, 1), generator=gen).float()], dim=1)
+    src = torch.randint(0, G, (P,), generator=gen)
+    pl = torch.cat([gtl[src, :4] + torch.randn(P, 4, generator=gen) * 6,
+                    torch.rand(P, 1, generator=gen),
+                    torch.where(torch.rand(P, 1, generator=gen) < 0.6, gtl[src, 4:5],
+                                torch.randint(0, ncls, (P, 1), generator=gen).float())], dim=1)
+    pl[::97, 4] = pl[1::97, 4][: pl[::97].shape[0]]              # confidence ties
+    return pl, gtl
+
+
+def _oracle_map_chunked(pl, gtl, ncls, thr, chunk=8192):
+    """ref_cpu.get_map with the P x G IoU table built a slice of predictions at a time."""
+    tp = np.concatenate([ref_cpu.true_positive_flags(pl[i:i + chunk], gtl, thr)
+                         for i in range(0, pl.shape[0], chunk)])
+    aps = np.array([ref_cpu.get_ap(pl, gtl, c, thr, tp) for c in range(ncls)])
+    s = 0
+    for a in aps:
+        s += a
+    return aps, s / ncls
+
+
+@pytest.mark.gpu
+def test_gpu_map_at_dataset_size(dev):
+    """A VOC-val-sized call: 100,000 detections against 5,000 ground truths (sorted by
+    class on the device), 20 classes -- float64 AP per class and mAP equal to the
+    oracle's bit for bit; and the direct path (few ground truths) at the same P."""
+    from yolo_amd import box_ops
+
+    for P, G, thr in ((100_000, 5_000, 4.0), (100_000, 300, 2.0), (4097, 2049, 6.0)):
+        pl, gtl = _random_problem(P, G, 20, seed=P + G)
+        want_ap, want_map = _oracle_map_chunked(pl, gtl, 20, thr)
+        ap, m = box_ops._map(pl.to(dev), gtl.to(dev), 20, thr)
+        np.testing.assert_array_equal(ap.cpu().numpy(), want_ap)
+        assert m.item() == want_map
+        assert want_map > 1e-4                                    # some true positives in every regime
+
+
+@pytest.mark.gpu
+def test_gpu_map_limits(dev):
+    from yolo_amd import _lib
+    lib = _lib.load()
+    f = 0x1000
+    assert lib.yh_map_11point(f, f, (1 << 24) + 1, 10, 20, 0.5, f, f, f, 1 << 30, None) == _lib.YH_ERR_UNSUPPORTED
+    assert lib.yh_map_11point(f, f, 10, 10, 20, 0.5, f, f, f, 16, None) == _lib.YH_ERR_WORKSPACE
+    assert lib.yh_map_workspace_bytes(1 << 20, 50_000) >= 5 * 4 * (1 << 20)

@@ -77,6 +77,7 @@ SIGNATURES = {
     "yh_scale_grad": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "yh_pairwise_boxes": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "yh_box_area": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "yh_map_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "yh_map_11point": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p,
                                c_void_p, c_void_p, c_size_t, c_void_p]),
     "yh_encode_targets": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

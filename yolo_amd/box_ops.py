@@ -66,7 +66,7 @@ def _map(pred, gt, n_classes, iou_thresh):
     dev = pred.device
     lib = _lib.load()
     p, g = pred.shape[0], gt.shape[0]
-    ws = torch.empty(lib.yh_workspace_bytes(_lib.YH_OP_MAP, p, 0, 0, 0), dtype=torch.uint8, device=dev)
+    ws = torch.empty(max(256, lib.yh_map_workspace_bytes(p, g)), dtype=torch.uint8, device=dev)
     ap = torch.empty(int(n_classes), dtype=torch.float64, device=dev)
     m = torch.empty((), dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):

@@ -1,84 +1,197 @@
-// 11-point mAP of eval.py:86-149 in three small launches:
-//   1  one lane per prediction: true-positive flag (pairwise IoU against the
-//      ground truths of its class, scaled by 8 as eval.py:99 does) and its rank
-//      by confidence; the class index of a true positive (else -1) is scattered
-//      to the rank position
-//   2  one workgroup per class: prefix count of that class's true positives over
+// 11-point mAP of eval.py:86-149 at dataset size:
+//   1  (many ground truths only) ground truths sorted by class, so that a
+//      prediction meets the ones of its own class only
+//   2  one lane per prediction: true-positive flag (IoU against the ground truths
+//      of its class, scaled by 8 as eval.py:99 does) -> the class index of a true
+//      positive, else -1; and its sort key, the confidence as an ordered integer
+//   3  device radix sort of (key, index), descending and stable: the
+//      confidence-descending order of eval.py:121 with equal confidences in index
+//      order (rocPRIM, caller-provided temporary storage)
+//   4  one workgroup per class: prefix count of that class's true positives over
 //      the ranked list, precision/recall in fp64 and the 11 recall-threshold maxima
-//   3  one lane: the mean over classes in class order
+//   5  one lane: the mean over classes in class order (the reference's own
+//      summation order, so that the float64 result is the same bits)
 #pragma once
 #include "head_math.hpp"
 
 namespace yh {
 
-__global__ __launch_bounds__(256) void map_rank_tp_kernel(const float* __restrict__ pred,
-                                                          const float* __restrict__ gt,
-                                                          long long P, long long G,
-                                                          float iou_thresh,
-                                                          int* __restrict__ ranked) {
-    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    const float* row = pred + p * 6;
-    const Box pb = {row[0], row[1], row[2], row[3]};
-    const float conf = row[4], clsf = row[5];
-    // eval.py:96-100: same class and 8 * IoU(gt, pred) >= threshold, for any ground truth
-    bool tp = false;
-    for (long long g = 0; g < G; ++g) {
-        const float* gr = gt + g * 5;
-        if (gr[4] == clsf) {
-            const Box gb = {gr[0], gr[1], gr[2], gr[3]};
-            tp = tp || (iou_pair(gb, pb) * 8.0f >= iou_thresh);
-        }
-    }
-    // eval.py:121: position in the confidence-descending order (ties: lower index first)
-    long long rank = 0;
-    for (long long q = 0; q < P; ++q) {
-        const float cq = pred[q * 6 + 4];
-        rank += (cq > conf || (cq == conf && q < p)) ? 1 : 0;
-    }
+constexpr int MAP_GT_DIRECT = 2048;   // up to here every prediction scans all ground truths
+
+// class of a row as an index, or -1 when it is not an integer in [0, n_classes)
+__device__ __forceinline__ int map_class_index(float clsf, int n_classes) {
     const int ci = (int)clsf;
-    ranked[rank] = (tp && (float)ci == clsf) ? ci : -1;
+    return ((float)ci == clsf && ci >= 0 && ci < n_classes) ? ci : -1;
 }
 
-__global__ __launch_bounds__(256) void map_ap_kernel(const int* __restrict__ ranked, long long P,
-                                                     long long G, double* __restrict__ ap_out) {
-    __shared__ int cnt[256];
-    __shared__ double best[256][11];
+__global__ __launch_bounds__(256) void map_gt_keys_kernel(const float* __restrict__ gt, long long G,
+                                                          int n_classes,
+                                                          unsigned int* __restrict__ keys,
+                                                          unsigned int* __restrict__ idx) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const int ci = map_class_index(gt[g * 5 + 4], n_classes);
+    keys[g] = ci < 0 ? 0xFFFFFFFFu : (unsigned int)ci;
+    idx[g] = (unsigned int)g;
+}
+
+// eval.py:96-100: a prediction is a true positive when ANY ground truth of its class
+// has 8 * IoU(gt, pred) >= threshold.  A prediction whose class is not an integer
+// in [0, n_classes) belongs to no class's list (eval.py:132 compares with the loop
+// index), so its flag is never looked at.
+// SORTED: gkeys/gidx are the ground truths' classes in ascending order and their
+// row numbers; else the ground truths pass through LDS, 256 at a time, and the
+// SL wavefront-aligned slices of a workgroup (256 / SL predictions each) share the
+// scan: slice s takes every SL-th ground truth, the flags are OR-ed in LDS.  Few
+// predictions then still fill the machine.
+template <bool SORTED, int SL>
+__global__ __launch_bounds__(256) void map_tp_key_kernel(
+    const float* __restrict__ pred, const float* __restrict__ gt, long long P, long long G,
+    int n_classes, float iou_thresh, const unsigned int* __restrict__ gkeys,
+    const unsigned int* __restrict__ gidx, int* __restrict__ tpcls,
+    unsigned int* __restrict__ keys, unsigned int* __restrict__ idx) {
+    constexpr int PB = 256 / SL;                       // predictions per workgroup
+    const int pl = threadIdx.x % PB, sl = threadIdx.x / PB;
+    const long long p = (long long)blockIdx.x * PB + pl;
+    const bool live = p < P;
+    Box pb = {0.f, 0.f, 0.f, 0.f};
+    float conf = 0.f, clsf = -1.f;
+    if (live) {
+        const float* row = pred + p * 6;
+        pb = {row[0], row[1], row[2], row[3]};
+        conf = row[4];
+        clsf = row[5];
+    }
+    const int ci = live ? map_class_index(clsf, n_classes) : -1;
+    bool tp = false;
+    if constexpr (SORTED) {
+        if (ci >= 0) {
+            // first ground truth of class ci
+            long long lo = 0, hi = G;
+            while (lo < hi) {
+                const long long mid = (lo + hi) >> 1;
+                if (gkeys[mid] < (unsigned int)ci) lo = mid + 1; else hi = mid;
+            }
+            for (long long g = lo; g < G && gkeys[g] == (unsigned int)ci; ++g) {
+                const float* gr = gt + (long long)gidx[g] * 5;
+                const Box gb = {gr[0], gr[1], gr[2], gr[3]};
+                tp = tp || (iou_pair(gb, pb) * 8.0f >= iou_thresh);
+            }
+        }
+    } else {
+        __shared__ float sgt[256 * 5];
+        __shared__ int anytp[PB];
+        if (SL > 1 && sl == 0) anytp[pl] = 0;
+        for (long long g0 = 0; g0 < G; g0 += 256) {
+            const int n = (int)(G - g0 < 256 ? G - g0 : 256);
+            __syncthreads();
+            for (int i = threadIdx.x; i < n * 5; i += 256) sgt[i] = gt[g0 * 5 + i];
+            __syncthreads();
+            if (ci >= 0) {
+                for (int g = sl; g < n; g += SL) {
+                    if (sgt[g * 5 + 4] == clsf) {
+                        const Box gb = {sgt[g * 5], sgt[g * 5 + 1], sgt[g * 5 + 2], sgt[g * 5 + 3]};
+                        tp = tp || (iou_pair(gb, pb) * 8.0f >= iou_thresh);
+                    }
+                }
+            }
+        }
+        if constexpr (SL > 1) {
+            if (tp) atomicOr(&anytp[pl], 1);
+            __syncthreads();
+            tp = anytp[pl] != 0;
+            if (sl != 0) return;
+        }
+    }
+    if (live) {
+        tpcls[p] = tp ? ci : -1;
+        // descending sort key; -0 counts as +0 and a NaN confidence ranks last
+        keys[p] = conf != conf ? 0u : float_to_ordered(conf + 0.0f);
+        idx[p] = (unsigned int)p;
+    }
+}
+
+// ranked[k] = class of the k-th ranked prediction if it is a true positive, else -1
+__global__ __launch_bounds__(256) void map_gather_kernel(const int* __restrict__ tpcls,
+                                                         const unsigned int* __restrict__ order,
+                                                         long long P, int* __restrict__ ranked) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < P) ranked[k] = tpcls[order[k]];
+}
+
+// One workgroup of 16 wavefronts per class.  A wavefront owns a contiguous span of
+// the ranked list and walks it 64 positions at a time (lane = position, coalesced):
+// the running count of the class's true positives is a ballot + popcount, carried
+// as a scalar; pass 1 gives every wavefront its starting count, pass 2 forms
+// precision and recall (fp64) at the true positives -- between two of them the
+// count stays and the precision only falls, so nothing else can raise a maximum
+// -- and keeps the 11 recall-threshold maxima per lane; positive doubles order as
+// integers, so the lanes merge theirs with an LDS integer max.
+// order[k] = row of the prediction ranked k-th; `ranked` (may be null) is the
+// gathered list tpcls[order[k]], used when given.
+constexpr int MAP_AP_THREADS = 1024;
+__global__ __launch_bounds__(MAP_AP_THREADS) void map_ap_kernel(
+    const int* __restrict__ tpcls, const unsigned int* __restrict__ order,
+    const int* __restrict__ ranked, long long P, long long G, double* __restrict__ ap_out) {
+    constexpr int NW = MAP_AP_THREADS / 64;
+    __shared__ long long wcnt[NW];
+    __shared__ unsigned long long lbest[11];
     const int c = blockIdx.x;
-    const int t = threadIdx.x;
-    const long long chunk = (P + 255) / 256;
-    const long long k0 = t * chunk;
-    const long long k1 = k0 + chunk < P ? k0 + chunk : P;
-    int local = 0;
-    for (long long k = k0; k < k1; ++k) local += ranked[k] == c ? 1 : 0;
-    cnt[t] = local;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x < 11) lbest[threadIdx.x] = 0ull;
+    const long long span = ((P + NW - 1) / NW + 63) / 64 * 64;
+    const long long k0 = w * span;
+    const long long k1 = k0 + span < P ? k0 + span : P;
+    auto is_tp = [&](long long k) -> bool {
+        if (k >= k1) return false;
+        return (ranked ? ranked[k] : tpcls[order[k]]) == c;
+    };
+    const bool short_span = span <= 256;     // the flags of pass 1 stay in registers for pass 2
+    bool f0 = false, f1 = false, f2 = false, f3 = false;
+    long long count = 0;
+    for (long long base = k0; base < k1; base += 256) {
+        // four rounds in flight
+        f0 = is_tp(base + lane); f1 = is_tp(base + 64 + lane); f2 = is_tp(base + 128 + lane);
+        f3 = is_tp(base + 192 + lane);
+        count += __popcll(__ballot(f0)) + __popcll(__ballot(f1)) + __popcll(__ballot(f2)) +
+                 __popcll(__ballot(f3));
+    }
+    if (lane == 0) wcnt[w] = count;
     __syncthreads();
-    long long tp = 0;                       // true positives ranked before this chunk
-    for (int w = 0; w < t; ++w) tp += cnt[w];
+    long long carry = 0;
+    for (int q = 0; q < w; ++q) carry += wcnt[q];
     double b[11];
 #pragma unroll
     for (int i = 0; i < 11; ++i) b[i] = 0.0;
-    for (long long k = k0; k < k1; ++k) {
-        tp += ranked[k] == c ? 1 : 0;
-        const double prec = (double)tp / (double)(k + 1);      // eval.py:124
-        const double rec = (double)tp / (double)G;             // eval.py:125 (0/0 -> NaN: never >=)
+    if (count > 0) {
+        int round = 0;
+        for (long long base = k0; base < k1; base += 64, ++round) {
+            const long long k = base + lane;
+            const bool v = short_span ? (round == 0 ? f0 : round == 1 ? f1 : round == 2 ? f2 : f3)
+                                      : is_tp(k);
+            const unsigned long long m = __ballot(v);
+            if (m == 0ull) continue;
+            if (v) {
+                const long long tp = carry + __popcll(m & ((2ull << lane) - 1ull));
+                const double prec = (double)tp / (double)(k + 1);      // eval.py:124
+                const double rec = (double)tp / (double)G;             // eval.py:125
 #pragma unroll
-        for (int i = 0; i < 11; ++i) {
-            const double thr = i == 10 ? 1.0 : (double)i * 0.1;   // np.linspace(0, 1, 11)
-            if (rec >= thr && prec > b[i]) b[i] = prec;
+                for (int i = 0; i < 11; ++i) {
+                    const double thr = i == 10 ? 1.0 : (double)i * 0.1;   // np.linspace(0, 1, 11)
+                    if (rec >= thr && prec > b[i]) b[i] = prec;
+                }
+            }
+            carry += __popcll(m);
         }
-    }
 #pragma unroll
-    for (int i = 0; i < 11; ++i) best[t][i] = b[i];
-    __syncthreads();
-    if (t < 11) {
-        double m = 0.0;
-        for (int w = 0; w < 256; ++w) m = best[w][t] > m ? best[w][t] : m;
-        best[0][t] = m;
+        for (int i = 0; i < 11; ++i)
+            if (b[i] > 0.0) atomicMax(&lbest[i], (unsigned long long)__double_as_longlong(b[i]));
     }
     __syncthreads();
-    if (t == 0) {
-        const double* p = best[0];
+    if (threadIdx.x == 0) {
+        double p[11];
+#pragma unroll
+        for (int i = 0; i < 11; ++i) p[i] = __longlong_as_double((long long)lbest[i]);
         // np.sum over 11 values: eight pairwise-combined accumulators, then the tail
         double r = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
         r += p[8];

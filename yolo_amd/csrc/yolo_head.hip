@@ -15,7 +15,6 @@
 #include "nms_kernels.hpp"
 #include "target_kernels.hpp"
 #include "box_kernels.hpp"
-#include "map_kernels.hpp"
 
 // Loss rows of yh_loss_fwd_bwd_static: device memory that belongs to the library
 // image itself, one copy per GPU at that GPU's own address.  In host code the
@@ -167,7 +166,7 @@ const char* yh_strerror(int rc) {
 
 size_t yh_workspace_bytes(int op, int64_t batch, int S, int Bx, int C) {
     (void)Bx; (void)C;
-    if (op == YH_OP_MAP) return batch < 1 ? 16 : (size_t)batch * sizeof(int);
+    if (op == YH_OP_MAP) return yh_map_workspace_bytes(batch, 0);   // few ground truths; else ask that function
     if ((op != YH_OP_LOSS && op != YH_OP_LOSS_PIPELINED) || batch < 0 || S < 1 || S > YH_MAX_S)
         return 0;
     const int64_t rows = loss_blocks(batch, S);
@@ -494,32 +493,6 @@ int yh_box_area(const float* ltrb, float* out, int64_t n, void* stream) {
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(yh::box_area_kernel, dim3((unsigned)blocks), dim3(256), 0,
                        (hipStream_t)stream, ltrb, out, (long long)n);
-    return launch_status();
-}
-
-int yh_map_11point(const float* pred, const float* gt, int64_t P, int64_t G, int n_classes,
-                   float iou_thresh, double* ap_out, double* map_out, void* workspace,
-                   size_t workspace_bytes, void* stream) {
-    if (P < 0 || G < 0 || n_classes < 1 || n_classes > 65535) return YH_ERR_SHAPE;
-    if (P > 16384) return YH_ERR_UNSUPPORTED;
-    if (isnan(iou_thresh)) return YH_ERR_ARG;
-    if (!ap_out || !map_out || (P > 0 && !pred) || (G > 0 && !gt)) return YH_ERR_NULL;
-    if (!workspace || workspace_bytes < yh_workspace_bytes(YH_OP_MAP, P, 0, 0, 0))
-        return YH_ERR_WORKSPACE;
-    if (!aligned(pred, 4) || !aligned(gt, 4) || !aligned(ap_out, 8) || !aligned(map_out, 8) ||
-        !aligned(workspace, 4))
-        return YH_ERR_ALIGN;
-    hipStream_t st = (hipStream_t)stream;
-    int* ranked = (int*)workspace;
-    if (P > 0) {
-        hipLaunchKernelGGL(yh::map_rank_tp_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0,
-                           st, pred, gt, (long long)P, (long long)G, iou_thresh, ranked);
-        if (const int rc = launch_status()) return rc;
-    }
-    hipLaunchKernelGGL(yh::map_ap_kernel, dim3((unsigned)n_classes), dim3(256), 0, st, ranked,
-                       (long long)P, (long long)G, ap_out);
-    if (const int rc = launch_status()) return rc;
-    hipLaunchKernelGGL(yh::map_mean_kernel, dim3(1), dim3(64), 0, st, ap_out, n_classes, map_out);
     return launch_status();
 }
 
