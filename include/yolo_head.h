@@ -49,7 +49,8 @@ extern "C" {
 #define YH_MAX_S 64
 #define YH_MAX_BX 16
 #define YH_MAX_C 4096
-#define YH_MAX_CANDIDATES 2048 /* per image, for the NMS entry points */
+#define YH_MAX_CANDIDATES 2048     /* per image, for the NMS entry points without a workspace */
+#define YH_MAX_CANDIDATES_WS 65536 /* per image, for yh_decode_nms_ws / yh_nms_ws (= 64*64*16) */
 
 /* op codes for yh_workspace_bytes */
 #define YH_OP_LOSS 0
@@ -326,7 +327,9 @@ int yh_decode_candidates(const float* pred, float* cand_ltrb, float* cand_score,
  *              eval.py:89-91 consumes) in that order, zero rows after them
  *   keep_count (batch) int32
  *   keep_idx   (batch, N) int32 flat index of each kept row, -1 after them; may be NULL
- * N = S*S*Bx <= YH_MAX_CANDIDATES.
+ * N = S*S*Bx <= YH_MAX_CANDIDATES (more: yh_decode_nms_ws).  The candidates of an
+ * image live in LDS: up to 36 bytes per candidate plus per-class tables, within the
+ * 160 KB of a gfx950 CU (YH_ERR_UNSUPPORTED when a shape would not fit).
  */
 int yh_decode_nms(const float* pred, float* dets, int32_t* keep_count, int32_t* keep_idx,
                   int mode, float conf_thresh, float iou_thresh, int64_t batch, int S, int Bx,
@@ -340,6 +343,32 @@ int yh_decode_nms(const float* pred, float* dets, int32_t* keep_count, int32_t* 
 int yh_nms(const float* cand_ltrb, const float* cand_score, const int32_t* cand_cls,
            const uint8_t* cand_present, float* dets, int32_t* keep_count, int32_t* keep_idx,
            float conf_thresh, float iou_thresh, int64_t batch, int N, void* stream);
+
+/*
+ * The NMS entry points for ANY shape the loss accepts (S <= 64, Bx <= 16: up to
+ * YH_MAX_CANDIDATES_WS = 65,536 candidates per image; the reference's
+ * post-processing has no size limit, model.py:379-394).  Up to
+ * YH_MAX_CANDIDATES per image they forward to yh_decode_nms /
+ * yh_decode_nms_linear (bias != NULL) / yh_nms, which keep an image's candidates in
+ * LDS, and the workspace may be NULL.  Above, the candidates go through global
+ * memory: boxes and 64-bit sort keys in the workspace, a device segmented radix
+ * sort (one segment per image), then one workgroup per image that walks each class
+ * in order against the rows it has already kept.  Same keep rule, row order and
+ * bits as yh_decode_nms / yh_nms.
+ *   workspace: yh_nms_workspace_bytes(batch, N, own_boxes) bytes, 256-byte aligned;
+ *   N = S*S*Bx and own_boxes = 1 for yh_decode_nms_ws, own_boxes = 0 for yh_nms_ws
+ *   (0 bytes when N <= YH_MAX_CANDIDATES).  These calls query the device on the
+ *   host (sort configuration): keep them out of graph capture.
+ */
+size_t yh_nms_workspace_bytes(int64_t batch, int N, int own_boxes);
+int yh_decode_nms_ws(const float* pred, const float* bias, float* dets, int32_t* keep_count,
+                     int32_t* keep_idx, int mode, float conf_thresh, float iou_thresh,
+                     int64_t batch, int S, int Bx, int C, int img_size, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int yh_nms_ws(const float* cand_ltrb, const float* cand_score, const int32_t* cand_cls,
+              const uint8_t* cand_present, float* dets, int32_t* keep_count, int32_t* keep_idx,
+              float conf_thresh, float iou_thresh, int64_t batch, int N, void* workspace,
+              size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

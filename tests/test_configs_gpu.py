@@ -98,9 +98,9 @@ def test_stress_shape_full_batch(dev):
 
 
 def test_maximum_sizes(dev):
-    """The limits the header states: S = 64, Bx = 16, C = 4096 for the loss and the
-    grid decode; S*S*Bx = 2,048 rows per image for the NMS entry points (S = 32 with two
-    predictors, S = 45 with one), beyond which they refuse."""
+    """The limits the header states: S = 64, Bx = 16, C = 4096 for the loss, the grid
+    decode and -- through the workspace entry points -- decode + NMS; S*S*Bx = 2,048 rows
+    per image for the NMS entry points without a workspace."""
     from yolo_amd import MODE_REFERENCE, _lib
     import numpy as np
     S, Bx, C = 64, 16, 4096
@@ -113,10 +113,24 @@ def test_maximum_sizes(dev):
     ltrb = head.get_ltrb(pred.to(dev))
     want = ref_cpu.get_ltrb(pred, S, Bx, 64 * 8)
     torch.testing.assert_close(ltrb.cpu(), want, rtol=1e-5, atol=2e-4)
+    # the entry point without a workspace stops at 2,048 candidates per image ...
     rc = _lib.load().yh_decode_nms(pred.to(dev).data_ptr(), 1, 1, None, 0, 0.5, 0.5, 1, S, Bx, C, 512, None)
     assert rc == _lib.YH_ERR_UNSUPPORTED
+    # ... postprocess goes on through yh_decode_nms_ws: the largest shape the loss takes
+    # (65,536 candidates per image) in both candidate modes
+    for mode in (MODE_DENSE, MODE_REFERENCE):
+        got = head.postprocess(pred.to(dev), 0.3, 0.5, mode, return_idx=True)
+        l, s, c, p = head.decode_candidates(pred.to(dev), mode)
+        want = ref_cpu.nms_batch(l.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy(), p.cpu().numpy(), 0.3, 0.5)
+        for g_, w in zip(got, want):
+            np.testing.assert_array_equal(g_.cpu().numpy().view(np.uint32), np.asarray(w).view(np.uint32))
+        assert int(got[1].sum()) > 1000
     for S, Bx, C, mode in ((32, 1, 4096, MODE_DENSE), (8, 16, 33, MODE_DENSE), (22, 2, 7, MODE_REFERENCE),
-                           (32, 2, 4096, MODE_DENSE), (32, 2, 7, MODE_REFERENCE), (45, 1, 11, MODE_DENSE)):
+                           (32, 2, 4096, MODE_DENSE), (32, 2, 7, MODE_REFERENCE), (45, 1, 11, MODE_DENSE),
+                           # above 2,048 candidates per image: few classes (long chains against
+                           # the kept rows), many classes, a bias folded in
+                           (64, 2, 20, MODE_DENSE), (64, 2, 3, MODE_REFERENCE), (33, 2, 300, MODE_DENSE),
+                           (23, 4, 5, MODE_DENSE), (64, 16, 20, MODE_DENSE)):
         head = YOLOv1Head(img_size=32 * S, n_cells=S, n_bboxes=Bx, n_classes=C)
         pred = synth.make_pred(2, S, Bx, C, seed=S + Bx).to(dev)
         got = head.postprocess(pred, 0.3, 0.5, mode, return_idx=True)

@@ -71,6 +71,10 @@ def test_decode_candidates_match_oracle(dev, mode):
     (2, 1500, 40, 0.001, 0.5),  # eight candidates per thread
     (2, 2048, 300, 0.0, 0.5),   # maximum size, short segments (pair path)
     (1, 2048, 3, 0.0, 0.4),     # maximum size, segments longer than 64 (step loop)
+    (3, 2049, 20, 0.1, 0.5),    # the first size of the global-memory path (yh_nms_ws)
+    (2, 5000, 1, 0.0, 0.5),     # one class: every chunk runs against all rows kept so far
+    (2, 8192, 4096, 0.0, 0.5),  # more classes than members per class
+    (1, 65536, 20, 0.2, 0.45),  # the largest size
 ])
 def test_nms_bit_exact(dev, batch, n, ncls, ct, it):
     ltrb, score, cls, present = random_candidates(batch, n, ncls, seed=n + batch)

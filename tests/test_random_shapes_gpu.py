@@ -29,8 +29,6 @@ def configs():
         Bx = int(rng.integers(1, 17 if wide else 6))
         C = int(rng.choice([1, 2, 3, 4, 7, 20, 21, 33, 64, 65, 80, 128, 129, 300] if wide
                            else [1, 2, 3, 4, 7, 20, 21, 33, 80, 100]))
-        if S * S * Bx > 2048:
-            continue
         batch = int(rng.choice([1, 2, 3, 5, 9, 17]))
         mode = int(rng.integers(0, 2))
         ct = float(rng.choice([0.001, 0.1, 0.3, 0.5, 0.7]))

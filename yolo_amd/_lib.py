@@ -37,6 +37,7 @@ YH_MODE_REFERENCE = 0
 YH_MODE_DENSE = 1
 
 YH_MAX_CANDIDATES = 2048
+YH_MAX_CANDIDATES_WS = 65536
 YH_STATIC_SCRATCH_BYTES = 262144
 
 YH_BOX_IOU = 0
@@ -94,6 +95,12 @@ SIGNATURES = {
                                      c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "yh_decode_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
                               c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "yh_nms_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "yh_decode_nms_ws": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
+                                 c_float, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
+                                 c_void_p]),
+    "yh_nms_ws": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                          c_float, c_float, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "yh_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                        c_float, c_float, c_int64, c_int, c_void_p]),
 }

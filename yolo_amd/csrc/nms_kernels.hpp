@@ -822,7 +822,7 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
 }
 
 // ---- candidates to global memory (the values nms_kernel<.,.,0> forms in registers) ---
-__global__ __launch_bounds__(256) void decode_candidates_kernel(
+static __global__ __launch_bounds__(256) void decode_candidates_kernel(
     const float* __restrict__ pred, float* __restrict__ c_ltrb, float* __restrict__ c_score,
     int32_t* __restrict__ c_cls, uint8_t* __restrict__ c_present, long long batch, int S,
     int nb, int nc, int mode, float cellf, float imgf) {

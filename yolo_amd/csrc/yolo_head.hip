@@ -53,6 +53,9 @@ inline int launch_status() {
 
 inline int round16(int x) { return (x + 15) & ~15; }
 
+// LDS of one gfx950 CU; a launch that asks for more is refused on the host
+constexpr size_t kLdsBudget = 160 * 1024;
+
 // workgroups of 256 threads for an elementwise kernel with a grid-stride loop
 inline unsigned grid_for(int64_t n) {
     int64_t b = (n + 255) / 256;
@@ -103,6 +106,7 @@ int launch_nms_shape(yh::NmsArgs a, hipStream_t st) {
         const int ipb = yh::NMS_BLOCK / NT;                                                 \
         const unsigned grid = (unsigned)((a.batch + ipb - 1) / ipb);                        \
         const size_t lds = (size_t)a.region_bytes * ipb;                                    \
+        if (lds > kLdsBudget) return YH_ERR_UNSUPPORTED;                                    \
         hipLaunchKernelGGL((yh::nms_kernel<NT, ITEMS, SRC, S_CT, BX_CT, C_CT>), dim3(grid), \
                            dim3(yh::NMS_BLOCK), lds, st, a);                                \
         return launch_status();                                                             \

@@ -610,14 +610,21 @@ class YOLOv1Head(nn.Module):
         count = torch.empty(bsz, dtype=torch.int32, device=dev)
         kidx = torch.empty(bsz, nn_, dtype=torch.int32, device=dev) if return_idx else None
         tail = (dets.data_ptr(), count.data_ptr(), _ptr(kidx), int(mode), float(conf_thresh),
-                float(iou_thresh), bsz, self.n_cells, self.n_bboxes, self.n_classes, self.img_size,
-                _stream(dev))
+                float(iou_thresh), bsz, self.n_cells, self.n_bboxes, self.n_classes, self.img_size)
+        lib = _lib.load()
+        if bias is not None:
+            bias = self._check_bias(bias, dev)
         with _on_device(dev):
-            if bias is None:
-                _lib.check(_lib.load().yh_decode_nms(out.data_ptr(), *tail))
+            if nn_ > _lib.YH_MAX_CANDIDATES:
+                # more candidates per image than a CU's LDS holds: the global-memory path
+                ws = torch.empty(max(256, lib.yh_nms_workspace_bytes(bsz, nn_, 1)), dtype=torch.uint8,
+                                 device=dev)
+                _lib.check(lib.yh_decode_nms_ws(out.data_ptr(), _ptr(bias), *tail, ws.data_ptr(),
+                                                ws.numel(), _stream(dev)))
+            elif bias is None:
+                _lib.check(lib.yh_decode_nms(out.data_ptr(), *tail, _stream(dev)))
             else:
-                bias = self._check_bias(bias, dev)
-                _lib.check(_lib.load().yh_decode_nms_linear(out.data_ptr(), bias.data_ptr(), *tail))
+                _lib.check(lib.yh_decode_nms_linear(out.data_ptr(), bias.data_ptr(), *tail, _stream(dev)))
         return (dets, count, kidx) if return_idx else (dets, count)
 
     @staticmethod
@@ -637,11 +644,16 @@ class YOLOv1Head(nn.Module):
         dets = torch.empty(bsz, n, 6, dtype=torch.float32, device=dev)
         count = torch.empty(bsz, dtype=torch.int32, device=dev)
         kidx = torch.empty(bsz, n, dtype=torch.int32, device=dev) if return_idx else None
+        lib = _lib.load()
         with _on_device(dev):
-            _lib.check(_lib.load().yh_nms(
+            ws = None
+            if n > _lib.YH_MAX_CANDIDATES:
+                ws = torch.empty(max(256, lib.yh_nms_workspace_bytes(bsz, n, 0)), dtype=torch.uint8,
+                                 device=dev)
+            _lib.check(lib.yh_nms_ws(
                 ltrb.data_ptr(), score.data_ptr(), cls.data_ptr(), _ptr(present),
                 dets.data_ptr(), count.data_ptr(), _ptr(kidx), float(conf_thresh),
-                float(iou_thresh), bsz, n, _stream(dev)))
+                float(iou_thresh), bsz, n, _ptr(ws), 0 if ws is None else ws.numel(), _stream(dev)))
         return (dets, count, kidx) if return_idx else (dets, count)
 
     def detections(self, out, conf_thresh=0.5, iou_thresh=0.5, mode=_lib.YH_MODE_REFERENCE):
