@@ -528,3 +528,24 @@ def test_gradient_buffer_not_16_byte_aligned(dev, S, Bx, C):
         assert (grad - outs[0][1]).abs().max().item() <= 1e-6 * scale
         if (S, Bx, C) != (7, 2, 20):
             assert torch.equal(grad, outs[0][1]) and torch.equal(terms, outs[0][0])
+
+
+def test_finalize_on_a_side_stream_back_to_back(dev):
+    """The scalar reduction on a side stream: consecutive calls share the head's
+    workspace, so each call must wait for the previous call's finalize before it
+    overwrites the rows, and `terms` must survive being freed early."""
+    head, ref_head = YOLOv1Head(), YOLOv1Head()
+    side = torch.cuda.Stream(dev)
+    sets = [tuple(x.to(dev) for x in synth.make_inputs(b, seed=400 + i))
+            for i, b in enumerate((4096, 7, 2048, 33, 4096, 1))]
+    want = [ref_head.loss_fwd_bwd(*s)[0].clone() for s in sets]
+    torch.cuda.synchronize()
+    for _ in range(3):
+        got = []
+        for s in sets:
+            terms, _ = head.loss_fwd_bwd(*s, finalize_stream=side)
+            got.append(terms)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        for g, w in zip(got, want):
+            assert torch.equal(g, w)

@@ -56,7 +56,11 @@ def test_last_box_in_a_cell_wins():
 @pytest.mark.gpu
 @pytest.mark.parametrize("S,C,img,batch,mb", [(7, 20, 448, 257, 5), (14, 80, 448, 33, 12),
                                                (3, 4, 96, 9, 3), (5, 7, 455, 17, 20), (7, 20, 448, 6, 70),
-                                               (7, 21, 448, 5, 1)])
+                                               (7, 21, 448, 5, 1),
+                                               # small grids with many boxes per image: the tiled
+                                               # kernel's LDS would not fit, the general one runs
+                                               (1, 5, 64, 300, 64), (2, 3, 64, 70, 64), (1, 2, 32, 1, 27),
+                                               (2, 4, 64, 65, 33)])
 def test_gpu_encoder_bit_exact(dev, S, C, img, batch, mb):
     from yolo_amd import YOLOv1Head
 

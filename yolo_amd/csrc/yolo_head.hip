@@ -512,9 +512,11 @@ int yh_encode_targets(const float* gt_ltrb, const int32_t* gt_label, const int32
         !aligned(gt_count, 4) || !aligned(gt_cls, 4))
         return YH_ERR_ALIGN;
     const int vec4 = (C % 4 == 0 && aligned(gt_cls, 16)) ? 1 : 0;
-    if (M >= 1 && M <= 64) {
-        const int g = loss_imgs_per_block(S);
-        const size_t lds = (size_t)g * M * 24 + (size_t)g * S * S * 4;
+    const int g = loss_imgs_per_block(S);
+    const size_t lds = (size_t)g * M * 24 + (size_t)g * S * S * 4;
+    // the tiled kernel keeps the boxes of its g images in LDS: small grids with many
+    // boxes per image (S = 1: g = 256) take the general kernel instead
+    if (M >= 1 && M <= 64 && lds <= 48 * 1024) {
         hipLaunchKernelGGL(yh::encode_targets_tiled_kernel, dim3((unsigned)((batch + g - 1) / g)),
                            dim3(256), lds, (hipStream_t)stream, gt_ltrb, gt_label, gt_count,
                            gt_xywh, gt_cls, obj_mask, (long long)batch, M, S, C,

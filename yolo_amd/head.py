@@ -172,6 +172,7 @@ class YOLOv1Head(nn.Module):
         self.backbone = backbone
         self.last_loss_terms: Optional[torch.Tensor] = None
         self._workspace = {}
+        self._fin_event = {}     # device -> event after the last side-stream finalize on its workspace
         self._pipe = {}          # device -> [workspace, phase of the last pipelined call]
         _lib.load()  # fail at construction time if the HIP library is missing
 
@@ -240,6 +241,10 @@ class YOLOv1Head(nn.Module):
             raise ValueError(f"loss log on {log.ring.device}, out is on {out.device}")
         with _on_device(out.device):
             st = _stream(out.device)
+            pending = self._fin_event.pop(out.device, None)
+            if pending is not None:
+                # a finalize on a side stream may still be reading the shared workspace
+                torch.cuda.current_stream(out.device).wait_event(pending)
             if log is None and finalize_stream is None:
                 _lib.check(lib.yh_loss_fwd_bwd(
                     out.data_ptr(), gt_norm_xywh.data_ptr(), gt_cls_prob.data_ptr(),
@@ -263,6 +268,15 @@ class YOLOv1Head(nn.Module):
                 terms.data_ptr(), None if log is None else log.ring.data_ptr(),
                 0 if log is None else log.capacity,
                 None if log is None else log.cursor.data_ptr(), fst))
+            if finalize_stream is not None:
+                # `terms` and the workspace were allocated on the current stream but are
+                # written / read on the side stream: tell the allocator, and make the next
+                # loss call on this device wait before it overwrites the workspace
+                terms.record_stream(finalize_stream)
+                ws.record_stream(finalize_stream)
+                ev = torch.cuda.Event()
+                ev.record(finalize_stream)
+                self._fin_event[out.device] = ev
         return terms, grad
 
     def loss_step_pipelined(self, out, gt_norm_xywh, gt_cls_prob, obj_mask, log: "LossLog",
@@ -332,9 +346,9 @@ class YOLOv1Head(nn.Module):
 
         ``finalize_stream``: stream for the small kernel that adds the per-workgroup
         loss rows.  Nothing downstream of the gradient needs the scalar, so it can
-        overlap whatever the current stream runs next; the caller makes the
-        current stream wait for it (``wait_stream``) before the next call of this
-        method or before reading ``terms``/the log."""
+        overlap whatever the current stream runs next.  The next loss call on this
+        device waits for it by itself (it shares the workspace); the caller makes
+        the current stream wait (``wait_stream``) before reading ``terms``/the log."""
         gb = out.shape[0] if global_batch is None else int(global_batch)
         return self._launch_loss(out.detach(), gt_norm_xywh, gt_cls_prob, obj_mask,
                                  1.0 / max(gb, 1), log, finalize_stream)
