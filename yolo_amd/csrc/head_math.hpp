@@ -116,42 +116,6 @@ __device__ __forceinline__ float iou_pair(const Box& p, const Box& g) {
     return uni == 0.0f ? 0.0f : inter / uni;
 }
 
-// "iou_pair(p, g) > thr" without the division.  The correctly rounded quotient
-// fl(inter / uni) exceeds thr exactly when the true quotient lies above the
-// midpoint `mid` of thr and the next float after it, or on that midpoint when
-// the tie goes up (round to nearest even: thr has an odd last bit).  mid has 25
-// significant bits and uni 24, so mid * uni is exact in fp64 and so is the
-// comparison with inter.  Thresholds outside [0, 1e30) take the division.
-struct IouGate {
-    double mid;
-    float thr;
-    int mode;   // 0: divide; 1: above iff inter > mid * uni; 2: above iff inter >= mid * uni
-};
-
-inline IouGate make_iou_gate(float thr) {
-    IouGate g = {0.0, thr, 0};
-    if (thr >= 0.0f && thr < 1e30f) {
-        const float up = nextafterf(thr, INFINITY);
-        uint32_t bits;
-        memcpy(&bits, &thr, sizeof bits);
-        g.mid = ((double)thr + (double)up) * 0.5;
-        g.mode = (bits & 1u) ? 2 : 1;
-    }
-    return g;
-}
-
-__device__ __forceinline__ bool iou_above(const Box& p, const Box& g, const IouGate& gate) {
-    const float a1 = box_area(p);
-    const float a2 = box_area(g);
-    const float iw = fmaxf(vmin_raw(p.r, g.r) - vmax_raw(p.l, g.l), 0.0f);
-    const float ih = fmaxf(vmin_raw(p.b, g.b) - vmax_raw(p.t, g.t), 0.0f);
-    const float inter = iw * ih;
-    const float uni = (a1 + a2) - inter;
-    if (gate.mode == 0) return (uni == 0.0f ? 0.0f : inter / uni) > gate.thr;
-    const double lhs = (double)inter, rhs = gate.mid * (double)uni;
-    return uni != 0.0f && (gate.mode == 1 ? lhs > rhs : lhs >= rhs);
-}
-
 // "iou_pair(p, g) > thr" for a wavefront: the quotient formed with v_rcp_f32 is
 // within 3e-7 relative of the correctly rounded one, so outside the band
 // [lo, hi] = thr * (1 -+ 2e-6) it decides; a lane inside the band (or with a

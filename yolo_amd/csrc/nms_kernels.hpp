@@ -47,7 +47,6 @@ struct NmsArgs {
     int nslot;  // candidate slots per image (S*S in reference mode, S*S*nb dense, N for source 1)
     int nout;   // rows of dets per image
     float cellf, imgf, conf_thr, iou_thr;
-    IouGate gate;   // iou_thr, prepared for the division-free comparison
     // per-image LDS region: byte offsets of the arrays inside it, and its size
     int off_keys, off_box, off_meta, off_seg, off_alive, off_misc, off_ccls, off_hist, off_segst, off_pair, off_kill;
     int region_bytes;
@@ -674,9 +673,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             // Pairs are numbered by later member, then by earlier member, so inside a
             // segment of L members the walk is register arithmetic: (ii, j) -> (ii + 1, j)
             // -> ... -> (0, j + 1); the next segment starts at sp + L, and its length is
-            // fetched one segment ahead.  The loop is bound by instruction issue (the
-            // other wavefronts of the SIMD cover the LDS latency), so it is written for
-            // instruction count: no prefetch registers, no division.
+            // fetched one segment ahead.
             const int p = lo;
             int sp = sseg[p];                     // first position of the segment
             int L = slen[sp];
@@ -684,10 +681,13 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             int ii = k - poff[p];                 // earlier member, ii < j
             int nL = sp + L < nvalid ? slen[sp + L] : 0;
             float4 bp = sbox[p];
-            const IouGate gate = a.gate;
+            const IouBand band = make_iou_band(a.iou_thr);
+            // The loop is bound by instruction issue (the other wavefronts of the SIMD cover
+            // the LDS latency; requesting the next pair's boxes ahead of the test was
+            // measured slower), so it is written for instruction count.
             for (; k < kend; ++k) {
                 const float4 b = sbox[sp + ii];
-                if (iou_above({b.x, b.y, b.z, b.w}, {bp.x, bp.y, bp.z, bp.w}, gate))
+                if (iou_above_band({b.x, b.y, b.z, b.w}, {bp.x, bp.y, bp.z, bp.w}, band))
                     atomicOr(&kills[sp + ii], 1ull << j);
                 if (++ii == j) {
                     ii = 0;

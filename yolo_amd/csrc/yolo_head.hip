@@ -651,7 +651,6 @@ int decode_nms_launch(const float* pred, const float* bias, float* dets, int32_t
     a.imgf = (float)img_size;
     a.conf_thr = conf_thresh;
     a.iou_thr = iou_thresh;
-    a.gate = yh::make_iou_gate(iou_thresh);
 #ifdef YH_PHASE_PROBE
     { const char* e = getenv("YH_NMS_STOP"); a.dbg_stop = e ? atoi(e) : 0; }
 #endif
@@ -701,7 +700,6 @@ int yh_nms(const float* cand_ltrb, const float* cand_score, const int32_t* cand_
     a.nout = N;
     a.conf_thr = conf_thresh;
     a.iou_thr = iou_thresh;
-    a.gate = yh::make_iou_gate(iou_thresh);
     return launch_nms<1>(a, (hipStream_t)stream);
 }
 
