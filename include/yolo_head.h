@@ -234,7 +234,9 @@ int yh_box_area(const float* ltrb, float* out, int64_t n, void* stream);
  *   ap_out (n_classes) float64, map_out (1) float64 (eval.py:142, :149).
  *   workspace: yh_map_workspace_bytes(P, G) bytes, 256-byte aligned: sort keys and
  *   the temporary storage of the device radix sort.  The call queries the device
- *   (occupancy) on the host: keep it out of graph capture.
+ *   (occupancy) on the host: keep it out of graph capture.  A small call (P <= 1024,
+ *   G <= 2048, n_classes <= 1024) is one launch of one workgroup that sorts in LDS and
+ *   does not touch the workspace; same bits either way.
  */
 #define YH_MAP_MAX_ROWS 16777216
 size_t yh_map_workspace_bytes(int64_t P, int64_t G);

@@ -84,7 +84,8 @@ def _random_problem(P, G, ncls, seed):
                     torch.rand(P, 1, generator=gen),
                     torch.where(torch.rand(P, 1, generator=gen) < 0.6, gtl[src, 4:5],
                                 torch.randint(0, ncls, (P, 1), generator=gen).float())], dim=1)
-    pl[::97, 4] = pl[1::97, 4][: pl[::97].shape[0]]              # confidence ties
+    n_tie = min(pl[::97].shape[0], pl[1::97].shape[0])
+    pl[::97][:n_tie, 4] = pl[1::97, 4][:n_tie]                   # confidence ties
     return pl, gtl
 
 
@@ -113,6 +114,34 @@ def test_gpu_map_at_dataset_size(dev):
         np.testing.assert_array_equal(ap.cpu().numpy(), want_ap)
         assert m.item() == want_map
         assert want_map > 1e-4                                    # some true positives in every regime
+
+
+@pytest.mark.gpu
+def test_gpu_map_small_calls(dev):
+    """Calls of at most 1,024 predictions run in one workgroup (one launch): ragged sizes,
+    ground truths in several LDS chunks, classes with far more than 64 true positives,
+    more classes than wavefronts, confidence ties and NaN confidences -- equal to the
+    oracle bit for bit, and to the four-kernel path on the same rows plus one."""
+    from yolo_amd import box_ops
+
+    for P, G, ncls, thr in ((1, 1, 3, 0.5), (63, 7, 20, 2.0), (1000, 300, 3, 1.0), (1024, 2048, 20, 4.0),
+                            (1024, 32, 1000, 2.0), (777, 700, 40, 3.0)):
+        pl, gtl = _random_problem(P, G, ncls, seed=7 * P + G)
+        if P > 100:
+            pl[5, 4] = float("nan")
+            pl[77, 4] = float("nan")
+            pl[9, 5] = 2.5                                        # not a class: belongs to no list
+        want_ap, want_map = _oracle_map_chunked(pl, gtl, ncls, thr)
+        ap, m = box_ops._map(pl.to(dev), gtl.to(dev), ncls, thr)
+        np.testing.assert_array_equal(ap.cpu().numpy(), want_ap)
+        assert m.item() == want_map, (P, G, ncls)
+    # the same rows through the general path: one more prediction that changes nothing
+    # it is ranked last (confidence NaN) and is no true positive
+    pl, gtl = _random_problem(1024, 200, 5, seed=11)
+    extra = torch.tensor([[0., 0., 1., 1., float("nan"), 0.]])
+    a1, m1 = box_ops._map(pl.to(dev), gtl.to(dev), 5, 1.0)
+    a2, m2 = box_ops._map(torch.cat([pl, extra]).to(dev), gtl.to(dev), 5, 1.0)
+    assert torch.equal(a1, a2) and m1.item() == m2.item() and m1.item() > 0.01
 
 
 @pytest.mark.gpu

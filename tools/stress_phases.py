@@ -1,0 +1,33 @@
+"""Phase timings of the stress-shape decode+NMS kernel from time stamps that thread 0
+of every workgroup takes at the phase boundaries (probe build: make -C yolo_amd/csrc
+probe; YOLO_AMD_LIB=build/libyolohead_probe.so)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from yolo_amd import YOLOv1Head, synth, MODE_DENSE
+dev = torch.device("cuda:0")
+B = int(os.environ.get("KB_BATCH", "1024"))
+S, BX, C, IMG = 14, 5, 80, 448
+head = YOLOv1Head(IMG, S, BX, C)
+pred = synth.make_inputs(B, S, BX, C, IMG)[0].to(dev)
+stamps = torch.zeros(B, 16, dtype=torch.int64, device=dev)
+for _ in range(5): head.postprocess(pred, 0.001, 0.5, MODE_DENSE)
+os.environ["YH_NMS_STAMPS"] = str(stamps.data_ptr())
+acc = torch.zeros(16, dtype=torch.float64)
+first = torch.zeros(16, dtype=torch.float64)
+N = 20
+for _ in range(N):
+    stamps.zero_()
+    head.postprocess(pred, 0.001, 0.5, MODE_DENSE)
+    torch.cuda.synchronize()
+    s = stamps.cpu().double()
+    t0 = s[:, 0].min()
+    acc += (s - t0).mean(0) / 100.0      # 100 MHz counter -> us
+names = ["entry", "class argmax", "decode+keys", "hist", "scan a", "scan b", "bucket scatter", "rank",
+         "C scatter", "numbering a", "numbering b", "pairs", "head list", "greedy walk", "alive", "output"]
+acc /= N
+prev = acc[0].item()
+print("variant", os.environ.get("YH_NMS_VARIANT", "0"), "mean start offset %.2f us" % prev)
+for i in range(1, 16):
+    print("  %-16s +%.2f us  (at %.2f)" % (names[i], acc[i].item() - prev, acc[i].item()))
+    prev = acc[i].item()

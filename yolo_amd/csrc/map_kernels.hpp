@@ -119,6 +119,29 @@ __global__ __launch_bounds__(256) void map_gather_kernel(const int* __restrict__
     if (k < P) ranked[k] = tpcls[order[k]];
 }
 
+// mean of the 11 interpolated precisions as np.sum forms it (eight pairwise-combined
+// accumulators, then the tail), divided by 11 (eval.py:142)
+__device__ __forceinline__ double map_mean_of_11(const double* p) {
+    double r = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    r += p[8];
+    r += p[9];
+    r += p[10];
+    return r / 11.0;
+}
+
+// Precision and recall of one true positive (fp64, eval.py:124-125) folded into the 11
+// recall-threshold maxima (np.linspace(0, 1, 11)).  tp = true positives of the class up
+// to and including this one, k = its 0-based rank among all predictions.
+__device__ __forceinline__ void map_fold_maxima(long long tp, long long k, long long G, double* b) {
+    const double prec = (double)tp / (double)(k + 1);
+    const double rec = (double)tp / (double)G;
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        const double thr = i == 10 ? 1.0 : (double)i * 0.1;
+        if (rec >= thr && prec > b[i]) b[i] = prec;
+    }
+}
+
 // One workgroup of 16 wavefronts per class.  A wavefront owns a contiguous span of
 // the ranked list and walks it 64 positions at a time (lane = position, coalesced):
 // the running count of the class's true positives is a ballot + popcount, carried
@@ -173,13 +196,7 @@ __global__ __launch_bounds__(MAP_AP_THREADS) void map_ap_kernel(
             if (m == 0ull) continue;
             if (v) {
                 const long long tp = carry + __popcll(m & ((2ull << lane) - 1ull));
-                const double prec = (double)tp / (double)(k + 1);      // eval.py:124
-                const double rec = (double)tp / (double)G;             // eval.py:125
-#pragma unroll
-                for (int i = 0; i < 11; ++i) {
-                    const double thr = i == 10 ? 1.0 : (double)i * 0.1;   // np.linspace(0, 1, 11)
-                    if (rec >= thr && prec > b[i]) b[i] = prec;
-                }
+                map_fold_maxima(tp, k, G, b);
             }
             carry += __popcll(m);
         }
@@ -192,12 +209,145 @@ __global__ __launch_bounds__(MAP_AP_THREADS) void map_ap_kernel(
         double p[11];
 #pragma unroll
         for (int i = 0; i < 11; ++i) p[i] = __longlong_as_double((long long)lbest[i]);
-        // np.sum over 11 values: eight pairwise-combined accumulators, then the tail
-        double r = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-        r += p[8];
-        r += p[9];
-        r += p[10];
-        ap_out[c] = r / 11.0;                                   // eval.py:142
+        ap_out[c] = map_mean_of_11(p);
+    }
+}
+
+// The whole metric in ONE workgroup for a small call (P <= MAP_SMALL_P predictions,
+// G <= MAP_GT_DIRECT ground truths, n_classes <= MAP_SMALL_CLASSES): one launch in
+// place of four.  Thread = prediction: true-positive flag against the ground truths
+// (through LDS, 256 at a time); a 64-bit key -- confidence as an ordered integer,
+// then the inverted row number (equal confidences in row order), then the payload
+// (class of a true positive + 1, else 0) in the low bits, which the unique bits
+// above keep out of the comparison; bitonic sort of the 1,024 keys, descending, a key
+// per thread in a register (partners 64 or more apart meet through LDS, closer ones
+// through wavefront shuffles); then a wavefront per class walks the ranked payloads
+// as map_ap_kernel does, and one lane adds the class values in class order.  Same
+// arithmetic, same bits as the four-kernel path.
+constexpr int MAP_SMALL_P = 1024;
+constexpr int MAP_SMALL_CLASSES = 1024;
+__global__ __launch_bounds__(MAP_SMALL_P) void map_small_kernel(
+    const float* __restrict__ pred, const float* __restrict__ gt, int P, int G, int n_classes,
+    float iou_thresh, double* __restrict__ ap_out, double* __restrict__ map_out) {
+    constexpr int NT = MAP_SMALL_P, NW = NT / 64;
+    __shared__ unsigned long long skey[NT];
+    __shared__ float sgt[256 * 5];
+    __shared__ int srk[NT];
+    __shared__ unsigned long long lbest[NW][11];
+    __shared__ double sap[MAP_SMALL_CLASSES];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const bool live = t < P;
+    Box pb = {0.f, 0.f, 0.f, 0.f};
+    float conf = 0.f, clsf = -1.f;
+    if (live) {
+        const float2* row = reinterpret_cast<const float2*>(pred + (long long)t * 6);   // 24-byte rows
+        const float2 r0 = row[0], r1 = row[1], r2 = row[2];
+        pb = {r0.x, r0.y, r1.x, r1.y};
+        conf = r2.x;
+        clsf = r2.y;
+    }
+    const int ci = live ? map_class_index(clsf, n_classes) : -1;
+    bool tp = false;
+    for (int g0 = 0; g0 < G; g0 += 256) {
+        const int n = G - g0 < 256 ? G - g0 : 256;
+        __syncthreads();
+        for (int i = t; i < n * 5; i += NT) sgt[i] = gt[(long long)g0 * 5 + i];
+        __syncthreads();
+        // The ground truths of the prediction's class first, as bit masks (a compare
+        // each), then IoU only for those: a wavefront runs as many IoU rounds as its
+        // busiest lane has matches, not as there are ground truths.
+        for (int q0 = 0; q0 < n; q0 += 64) {
+            const int nq = n - q0 < 64 ? n - q0 : 64;
+            unsigned long long match = 0ull;
+            if (ci >= 0)
+                for (int g = 0; g < nq; ++g)
+                    match |= (unsigned long long)(sgt[(q0 + g) * 5 + 4] == clsf) << g;
+            while (__ballot(match != 0ull)) {
+                if (match) {
+                    const int g = q0 + __ffsll((long long)match) - 1;
+                    match &= match - 1ull;
+                    const Box gb = {sgt[g * 5], sgt[g * 5 + 1], sgt[g * 5 + 2], sgt[g * 5 + 3]};
+                    tp = tp || (iou_pair(gb, pb) * 8.0f >= iou_thresh);
+                }
+            }
+        }
+    }
+    // [63:32] confidence (-0 counts as +0, NaN ranks last), [31:21] inverted row, [20:0] payload;
+    // rows beyond P carry zeros above an inverted row that is lower than any real one
+    const unsigned int ckey = !live || conf != conf ? 0u : float_to_ordered(conf + 0.0f);
+    const unsigned int payload = tp ? (unsigned int)(ci + 1) : 0u;
+    unsigned long long v = ((unsigned long long)ckey << 32) |
+                           ((unsigned long long)((unsigned int)(NT - 1 - t) & 0x7FFu) << 21) | payload;
+    for (int k = 2; k <= NT; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            unsigned long long o;
+            if (j >= 64) {
+                __syncthreads();
+                skey[t] = v;
+                __syncthreads();
+                o = skey[t ^ j];
+            } else {
+                o = __shfl_xor(v, j, 64);
+            }
+            const bool keep_max = ((t & j) == 0) == ((t & k) == 0);
+            v = keep_max ? (v > o ? v : o) : (v < o ? v : o);
+        }
+    }
+    srk[t] = (int)(v & 0x1FFFFFu);
+    __syncthreads();
+    // A wavefront per class.  First the ranks of the class's true positives are listed
+    // (ballot + popcount, in rank order); then lane j takes the j-th of them -- j + 1 true
+    // positives at that rank -- so the fp64 quotients are formed for true positives only.
+    int* hits = reinterpret_cast<int*>(skey) + w * 64;    // the sort is over: 64 ranks per wavefront
+    for (int c = w; c < n_classes; c += NW) {
+        if (lane < 11) lbest[w][lane] = 0ull;
+        double b[11];
+#pragma unroll
+        for (int i = 0; i < 11; ++i) b[i] = 0.0;
+        int nh = 0;           // ranks listed and not yet folded (at most 64)
+        long long done = 0;   // true positives already folded
+        auto fold_listed = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < nh) map_fold_maxima(done + lane + 1, hits[lane], G, b);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            done += nh;
+            nh = 0;
+        };
+        for (int base = 0; base < P; base += 64) {
+            const int k = base + lane;
+            const bool hit = k < P && srk[k] == c + 1;
+            const unsigned long long m = __ballot(hit);
+            const int cnt = __popcll(m);
+            if (nh + cnt > 64) fold_listed();
+            if (hit) hits[nh + __popcll(m & ((1ull << lane) - 1ull))] = k;
+            nh += cnt;
+        }
+        if (nh > 0) fold_listed();
+        if (done > 0) {
+#pragma unroll
+            for (int i = 0; i < 11; ++i)
+                if (b[i] > 0.0) atomicMax(&lbest[w][i], (unsigned long long)__double_as_longlong(b[i]));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            double p[11];
+#pragma unroll
+            for (int i = 0; i < 11; ++i) p[i] = __longlong_as_double((long long)lbest[w][i]);
+            const double ap = map_mean_of_11(p);
+            ap_out[c] = ap;
+            sap[c] = ap;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    if (t == 0) {
+        double s = 0.0;
+        for (int c = 0; c < n_classes; ++c) s += sap[c];          // eval.py:146-148
+        *map_out = s / (double)n_classes;                         // eval.py:149
     }
 }
 

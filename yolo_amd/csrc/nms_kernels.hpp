@@ -51,7 +51,19 @@ struct NmsArgs {
     int off_keys, off_box, off_meta, off_seg, off_alive, off_misc, off_ccls, off_hist, off_segst, off_pair, off_kill;
     int region_bytes;
     int dbg_stop;  // builds with -DYH_PHASE_PROBE only: leave after this phase (0 = run everything)
+    // builds with -DYH_PHASE_PROBE only: 16 time stamps per workgroup (100 MHz counter)
+    unsigned long long* stamps;
 };
+
+#ifdef YH_PHASE_PROBE
+#define YH_STAMP(i)                                                                        \
+    do {                                                                                   \
+        if (a.stamps && threadIdx.x == 0)                                                  \
+            a.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime();    \
+    } while (0)
+#else
+#define YH_STAMP(i) do {} while (0)
+#endif
 
 // ---- decode primitives shared by every kernel that forms candidates --------------
 // `logit(ch)` returns channel ch of the cell: from registers when the shape is a
@@ -179,6 +191,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
     const int S = S_CT > 0 ? S_CT : a.S;
     const int S2 = S * S;
 
+    YH_STAMP(0);
     // ---- phase A: candidates ---------------------------------------------------
     Box cbox[ITEMS];
     float cscore[ITEMS];
@@ -270,6 +283,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                 }
             }
             group_sync<NT>();
+            YH_STAMP(1);
 #pragma unroll
             for (int e = 0; e < ITEMS; ++e) {
                 const int n = e * NT + t;
@@ -418,6 +432,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         }
     }
     group_sync<NT>();
+    YH_STAMP(2);
     int rank[ITEMS], seg[ITEMS];
 #pragma unroll
     for (int e = 0; e < ITEMS; ++e) { rank[e] = 0; seg[e] = 0; }
@@ -445,6 +460,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         for (int e = 0; e < ITEMS; ++e)
             if (cvalid[e]) atomicAdd(&hist[ccl[e]], 1);
         group_sync<NT>();
+        YH_STAMP(3);
         // exclusive prefix sum over the classes: a contiguous chunk per thread,
         // shuffle scan per wavefront, carries through LDS
         const int chunk = (nc + NT - 1) / NT;
@@ -460,6 +476,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         }
         if (lane == 63) wtot[wv] = incl;
         group_sync<NT>();
+        YH_STAMP(4);
         int run = incl - local;
         for (int w = 0; w < wv; ++w) run += wtot[w];
         for (int q = 0; q < chunk; ++q) {
@@ -472,10 +489,12 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             }
         }
         group_sync<NT>();
+        YH_STAMP(5);
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e)
             if (cvalid[e]) keys[segst[ccl[e]] + atomicAdd(&hist[ccl[e]], 1)] = key[e];
         group_sync<NT>();
+        YH_STAMP(6);
         // rank inside the bucket; the bucket order itself does not matter
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
@@ -503,6 +522,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
 #ifdef YH_PHASE_PROBE
     if (a.dbg_stop == 2) { if (rank[0] == 12345) a.keep_count[img] = seg[0]; return; }
 #endif
+    YH_STAMP(7);
     // ---- phase C: scatter to rank order ---------------------------------------------
     int nv_local = 0, mp_local = 0;
 #pragma unroll
@@ -523,6 +543,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         }
     }
     group_sync<NT>();
+    YH_STAMP(8);
     const int nvalid = kWave ? nvalid_w : misc[0];
     int maxpos = kWave ? 0 : misc[1];
 
@@ -639,6 +660,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         }
         if (t == 0) misc[2] = 0;   // number of segment heads queued below
         group_sync<NT>();
+        YH_STAMP(9);
         int npairs = 0;
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
@@ -657,6 +679,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             }
         }
         group_sync<NT>();
+        YH_STAMP(10);
 #ifdef YH_PHASE_PROBE
         if (a.dbg_stop == 5) return;
 #endif
@@ -707,6 +730,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             }
         }
         group_sync<NT>();
+        YH_STAMP(11);
 #ifdef YH_PHASE_PROBE
         if (a.dbg_stop == 6) return;
 #endif
@@ -718,6 +742,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             if (al[e] && r[e] == 0) hlist[atomicAdd(&misc[2], 1)] = i;
         }
         group_sync<NT>();
+        YH_STAMP(12);
         // one lane per segment: greedy pass over its members, eight words per round trip
         const int nheads = misc[2];
         for (int h = t; h < nheads; h += NT) {
@@ -735,6 +760,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             kills[head] = dead;
         }
         group_sync<NT>();
+        YH_STAMP(13);
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
             if (al[e] && ((kills[mymeta[e].w] >> r[e]) & 1ull)) al[e] = false;
@@ -742,6 +768,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             if (lane == 0) alive[e * NW + wv] = w;
         }
         group_sync<NT>();
+        YH_STAMP(14);
 #pragma unroll
         for (int w = 0; w < ITEMS * NW; ++w) total += __popcll(alive[w]);
 #pragma unroll
@@ -813,6 +840,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
     if (kd)
         for (int i = total + t; i < nout; i += NT) kd[i] = -1;
     if (t == 0) a.keep_count[img] = total;
+    YH_STAMP(15);
 }
 
 template <int NT, int ITEMS, int SRC, int S_CT, int BX_CT, int C_CT>

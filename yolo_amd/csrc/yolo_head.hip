@@ -653,6 +653,7 @@ int decode_nms_launch(const float* pred, const float* bias, float* dets, int32_t
     a.iou_thr = iou_thresh;
 #ifdef YH_PHASE_PROBE
     { const char* e = getenv("YH_NMS_STOP"); a.dbg_stop = e ? atoi(e) : 0; }
+    { const char* e = getenv("YH_NMS_STAMPS"); a.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
 #endif
     return with_bias ? launch_nms<2>(a, (hipStream_t)stream) : launch_nms<0>(a, (hipStream_t)stream);
 }

@@ -93,6 +93,12 @@ int yh_map_11point(const float* pred, const float* gt, int64_t P, int64_t G, int
     int* tpcls = (int*)(ws + l.tpcls);
     void* temp = ws + l.temp;
     size_t temp_bytes = l.temp_bytes;
+    if (P <= yh::MAP_SMALL_P && G <= yh::MAP_GT_DIRECT && n_classes <= yh::MAP_SMALL_CLASSES) {
+        // a small call: everything in one workgroup, one launch (the workspace is not used)
+        hipLaunchKernelGGL(yh::map_small_kernel, dim3(1), dim3(yh::MAP_SMALL_P), 0, st, pred, gt, (int)P,
+                           (int)G, n_classes, iou_thresh, ap_out, map_out);
+        return launch_status();
+    }
     if (P > 0) {
         const unsigned grid = (unsigned)((P + 255) / 256);
         if (G > yh::MAP_GT_DIRECT) {
