@@ -31,3 +31,8 @@ print("variant", os.environ.get("YH_NMS_VARIANT", "0"), "mean start offset %.2f 
 for i in range(1, 16):
     print("  %-16s +%.2f us  (at %.2f)" % (names[i], acc[i].item() - prev, acc[i].item()))
     prev = acc[i].item()
+# spread over the workgroups of the last launch: when each one starts, leaves the memory phase and ends
+s = (stamps.cpu().double() - stamps.cpu().double()[:, 0].min()) / 100.0
+for name, col in (("start", 0), ("memory phase done", 2), ("pairs done", 11), ("end", 15)):
+    q = torch.quantile(s[:, col], torch.tensor([0.0, 0.1, 0.5, 0.9, 1.0], dtype=torch.float64))
+    print("  %-18s min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f us" % ((name,) + tuple(q.tolist())))
