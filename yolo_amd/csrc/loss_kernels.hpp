@@ -20,6 +20,18 @@ namespace yh {
 
 constexpr int LOSS_THREADS = 256;
 
+#ifdef YH_PHASE_PROBE
+// probe builds only: eight time stamps per workgroup (100 MHz counter) of loss_block
+__device__ unsigned long long* yh_loss_stamps = nullptr;
+#define YH_LSTAMP(i)                                                                        \
+    do {                                                                                    \
+        if (yh_loss_stamps && threadIdx.x == 0)                                             \
+            yh_loss_stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define YH_LSTAMP(i) do {} while (0)
+#endif
+
 
 // A cell without object: only the no-object confidence term (model.py:270-274);
 // every other gradient of the cell is zero.  `logit(ch)` returns channel ch of
@@ -703,6 +715,7 @@ __device__ __forceinline__ void loss_block(
     // the global addresses.
     const long long gbase = img0 * (long long)D * S2;
     const int pad = (int)(gbase & 3);
+    YH_LSTAMP(0);
 
     // Pass 1, one lane per cell: cells without an object are finished here (two
     // confidence logits in, their gradients into the tile); cells with one are only
@@ -760,10 +773,12 @@ __device__ __forceinline__ void loss_block(
             }
         }
     }
+    YH_LSTAMP(1);
     const unsigned long long omask = __ballot(has_obj);
     if (has_obj) olist[wave * 64 + __popcll(omask & ((1ull << lane) - 1ull))] = threadIdx.x;
     if (lane == 0) wcount[wave] = __popcll(omask);
     __syncthreads();
+    YH_LSTAMP(2);
     {
         int cnt[LOSS_THREADS / 64];
         int total_obj = 0;
@@ -798,7 +813,9 @@ __device__ __forceinline__ void loss_block(
                                     BX, C, cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf, acc_cls);
         }
     }
+    YH_LSTAMP(3);
     loss_block_reduce(acc_coord, acc_conf, acc_cls, partials, bid);   // has a barrier after the LDS writes
+    YH_LSTAMP(4);
     {
         const long long left = batch - img0;
         const int n = (int)(left < IPB ? left : IPB) * (D * S2);   // floats of this block
@@ -813,6 +830,7 @@ __device__ __forceinline__ void loss_block(
         const int done = head + 4 * n4;
         if ((int)threadIdx.x < n - done) gout[done + threadIdx.x] = sgrad[pad + done + threadIdx.x];
     }
+    YH_LSTAMP(5);
 }
 
 template <int S, int BX, int C, bool PIPE, bool BIAS>

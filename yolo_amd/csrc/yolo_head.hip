@@ -148,6 +148,13 @@ extern "C" {
 
 int yh_version(void) { return YH_VERSION; }
 
+#ifdef YH_PHASE_PROBE
+// probe builds only: where loss_block leaves its time stamps (nullptr: nowhere)
+int yh_probe_set_loss_stamps(void* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(yh::yh_loss_stamps), &p, sizeof(p));
+}
+#endif
+
 const char* yh_strerror(int rc) {
     switch (rc) {
         case YH_OK: return "ok";
