@@ -340,6 +340,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             unsigned long long* killt = reinterpret_cast<unsigned long long*>(region + a.off_kill);
             unsigned long long* hight = killt + 64;
             float* sscore = reinterpret_cast<float*>(smeta);
+            YH_STAMP(2);
             const unsigned long long me = 1ull << lane;
             const bool valid = cvalid[0];
             const float myscore = cscore[0];
@@ -375,6 +376,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                 }
             }
             group_sync<NT>();
+            YH_STAMP(3);
             const unsigned long long killers = killt[lane], higher = hight[lane];
             unsigned long long undec = __ballot(valid), kept = 0ull;
             while (undec) {
@@ -385,6 +387,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                 kept |= km;
                 undec &= ~(km | __ballot(die));
             }
+            YH_STAMP(4);
             // kept lanes per class -> first output row of each class
             int* cbase = sseg;
             cbase[lane] = wave_excl_scan(lane < nc_tab ? __popcll(keys[lane] & kept) : 0);
@@ -406,6 +409,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             if (kd)
                 for (int i = total + t; i < nout; i += NT) kd[i] = -1;
             if (t == 0) a.keep_count[img] = total;
+            YH_STAMP(15);
             return;
         }
     }
