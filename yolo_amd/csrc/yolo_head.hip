@@ -165,7 +165,10 @@ const char* yh_strerror(int rc) {
         case YH_ERR_WORKSPACE: return "yolo_head: workspace missing or too small";
         case YH_ERR_ALIGN: return "yolo_head: pointer not aligned as documented";
         case YH_ERR_ARG: return "yolo_head: invalid scalar argument";
-        case YH_ERR_UNSUPPORTED: return "yolo_head: more than 2048 candidates per image";
+        case YH_ERR_UNSUPPORTED:
+            return "yolo_head: more candidates per image (or rows) than this entry point takes, or a shape "
+                   "whose per-image tables do not fit the 160 KB of LDS; see the limits in yolo_head.h "
+                   "(yh_decode_nms_ws / yh_nms_ws take up to 65,536 candidates per image)";
         case YH_ERR_SCRATCH:
             return "yolo_head: the batch needs more loss rows than the static scratch array holds "
                    "(or its device address could not be resolved)";
