@@ -115,6 +115,24 @@ int yh_loss_fwd_bwd_static(const float* pred, const float* gt_xywh, const float*
                            float lambda_noobj, float inv_global_batch, void* stream);
 
 /*
+ * The loss and the fused decode + NMS on a CELL-MAJOR head tensor: pred and grad_pred are
+ * (batch, S, S, D) -- cell i*S + j of an image holds its D values consecutively, in the
+ * channel order of model.py:140-142 -- which is the memory of a channels-last
+ * (batch, D, S, S) tensor, for backbones that end in a channels-last convolution instead of
+ * the reference's Linear + view (model.py:133-135, 146-148).  Everything else as
+ * yh_loss_fwd_bwd / yh_decode_nms (same arithmetic per cell; the run-time-shape kernels do
+ * the work for every shape).
+ */
+int yh_loss_fwd_bwd_nhwc(const float* pred, const float* gt_xywh, const float* gt_cls,
+                         const uint8_t* obj_mask, float* grad_pred, float* loss_terms,
+                         void* workspace, size_t workspace_bytes, int64_t batch, int S, int Bx,
+                         int C, int img_size, float lambda_coord, float lambda_noobj,
+                         float inv_global_batch, void* stream);
+int yh_decode_nms_nhwc(const float* pred, float* dets, int32_t* keep_count, int32_t* keep_idx,
+                       int mode, float conf_thresh, float iou_thresh, int64_t batch, int S, int Bx,
+                       int C, int img_size, void* stream);
+
+/*
  * The two halves of yh_loss_fwd_bwd as separate launches, for callers that put
  * the scalar reduction on another stream (nothing downstream of the gradient
  * depends on it) or log the loss on the device.

@@ -55,6 +55,11 @@ SIGNATURES = {
     "yh_loss_fwd_bwd_static": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_int64, c_int, c_int, c_int, c_int, c_float, c_float,
                                        c_float, c_void_p]),
+    "yh_loss_fwd_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_int,
+                                     c_float, c_float, c_float, c_void_p]),
+    "yh_decode_nms_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
+                                   c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "yh_loss_partials": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_size_t, c_int64, c_int, c_int, c_int, c_int, c_float, c_float,
                                  c_float, c_void_p]),

@@ -548,6 +548,10 @@ __device__ __forceinline__ void loss_pipe_log(const LossPipe& p, int own_rows, f
 // Run-time shape (any S, Bx, C within the limits): channels are read on use.
 // BIAS: `pred` is the last layer's output before its bias (model.py:133-135) and
 // `bias` (one image's worth of values, same layout) is added as the logits are read.
+// NHWC: the head tensor and its gradient are cell-major, (batch, S, S, D) -- a cell's D
+// values are consecutive and cells are D floats apart (the memory of a channels-last
+// (batch, D, S, S) tensor); otherwise channel-major as everywhere else.  An image is
+// the same contiguous block of D * S * S floats either way, so the tile serves both.
 // TILE: the workgroup's gradients -- one contiguous block of the tensor -- are
 // collected in LDS (dynamic, loss_generic_tile_floats() floats) and leave in
 // 16-byte stores; `grad` must be 16-byte aligned and the workgroup must own at
@@ -559,7 +563,7 @@ inline long long loss_generic_tile_floats(int imgs_per_block, int S, int nb, int
     return (long long)imgs_per_block * (5 * nb + nc) * S * S + 4;
 }
 
-template <bool PIPE, bool BIAS, bool TILE>
+template <bool PIPE, bool BIAS, bool TILE, bool NHWC = false>
 __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
     const float* __restrict__ pred, const float* __restrict__ bias,
     const float* __restrict__ gt_xywh,
@@ -578,6 +582,9 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
     }
     const int S2 = S * S;
     const long long D = 5 * nb + nc;
+    // floats between two channels of a cell, and between two cells of a channel
+    const int chs = NHWC ? 1 : S2;
+    const int cls_ = NHWC ? (int)D : 1;
     const long long img0 = (long long)bid * imgs_per_block;
     const int nitems = imgs_per_block * S2;       // <= max(LOSS_THREADS, YH_MAX_S^2) = 4096
     // Pass 1, one lane per cell: a cell without an object is finished (its confidence
@@ -608,11 +615,11 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
             if (img < batch) {
                 has_obj = obj_mask[img * S2 + cell] != 0;
                 if (!has_obj) {
-                    const long long off = img * D * S2 + cell;
-                    const GlobalLogits<BIAS> logit{pred + off, BIAS ? bias + cell : nullptr, S2};
+                    const long long off = img * D * S2 + cell * cls_;
+                    const GlobalLogits<BIAS> logit{pred + off, BIAS ? bias + cell : nullptr, chs};
                     float* g = grad + off;
-                    if constexpr (TILE) g = gtile + pad + gi * DS2 + cell;
-                    loss_noobj_cell_rt(logit, g, S2, nb, nc, ln, inv_gb, acc_conf);
+                    if constexpr (TILE) g = gtile + pad + gi * DS2 + cell * cls_;
+                    loss_noobj_cell_rt(logit, g, chs, nb, nc, ln, inv_gb, acc_conf);
                 }
             }
         }
@@ -639,11 +646,11 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
             const int cell = item - gi * S2;
             const long long img = img0 + gi;
             const long long tcell = img * S2 + cell;
-            const long long off = img * D * S2 + cell;
-            const GlobalLogits<BIAS> logit{pred + off, BIAS ? bias + cell : nullptr, S2};
+            const long long off = img * D * S2 + cell * cls_;
+            const GlobalLogits<BIAS> logit{pred + off, BIAS ? bias + cell : nullptr, chs};
             float* g = grad + off;
-            if constexpr (TILE) g = gtile + pad + gi * DS2 + cell;
-            loss_obj_cell_wave<GW>(logit, g, gt_xywh + tcell * 4, gt_cls + tcell * nc, cell, S, S2,
+            if constexpr (TILE) g = gtile + pad + gi * DS2 + cell * cls_;
+            loss_obj_cell_wave<GW>(logit, g, gt_xywh + tcell * 4, gt_cls + tcell * nc, cell, S, chs,
                                    nb, nc, cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf,
                                    acc_cls);
         };

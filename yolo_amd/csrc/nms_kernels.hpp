@@ -44,6 +44,9 @@ struct NmsArgs {
     int32_t* keep_idx;
     long long batch;
     int S, nb, nc, mode;
+    // 1: the head tensor is cell-major, (batch, S, S, D) -- a cell's D values consecutive
+    // (run-time-shape kernels only); 0: channel-major
+    int cell_major;
     int nslot;  // candidate slots per image (S*S in reference mode, S*S*nb dense, N for source 1)
     int nout;   // rows of dets per image
     float cellf, imgf, conf_thr, iou_thr;
@@ -158,8 +161,9 @@ __device__ __forceinline__ void group_sync() {
 // cell is a constant offset; 0: run-time); SRC 1: candidates loaded from memory.
 // The work of workgroup `block_id` of the NMS grid; `smem` is its LDS
 // (region_bytes per image it holds).
-template <int NT, int ITEMS, int SRC, int S_CT, int BX_CT, int C_CT>
+template <int NT, int ITEMS, int SRC, int S_CT, int BX_CT, int C_CT, bool CM = false>
 __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsigned char* smem) {
+    static_assert(!CM || (S_CT == 0 && SRC == 0), "cell-major tensors take the run-time-shape path");
     constexpr int IPB = NMS_BLOCK / NT;  // images per workgroup
     constexpr bool kHead = SRC == 0 || SRC == 2;   // candidates decoded from the head tensor
     constexpr bool kBias = SRC == 2;               // ... to which a bias is added on the way in
@@ -212,13 +216,17 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         const int nc = kStatic ? C_CT : a.nc;
         const long long D = 5 * nb + nc;
         const float* pimg = a.pred + img * D * S2;
+        // floats between two channels of a cell and between two cells of a channel; with
+        // CM the channel stride is the constant 1, so a lane's loads can be merged
+        const int chs = CM ? 1 : S2;
+        const int cells = CM ? (int)D : 1;
         if (a.mode == 0) {
             // slot = cell; the higher-confidence predictor is the candidate
 #pragma unroll
             for (int e = 0; e < ITEMS; ++e) {
                 const int cell = e * NT + t;
                 if (cell < nslot) {
-                    const float* p = pimg + cell;
+                    const float* p = pimg + cell * cells;
                     float cb;
                     int k;
                     if constexpr (kStaticCell) {
@@ -249,7 +257,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                         cbox[e] = box_from_logits(lx, ly, lw, lh, cell, S, a.cellf, a.imgf);
                         ccl[e] = cell_class(logit, 5 * BX_CT, C_CT);
                     } else {
-                        const MemLogitsT<kBias> logit{p, kBias ? a.bias + cell : nullptr, S2};
+                        const MemLogitsT<kBias> logit{p, kBias ? a.bias + cell : nullptr, chs};
                         k = cell_best_conf(logit, nb, cb);
                         cbox[e] = cell_box(logit, k, cell, S, a.cellf, a.imgf);
                         ccl[e] = cell_class_mem(logit, 5 * nb, nc);
@@ -265,7 +273,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             for (int e = 0; e < ITEMS; ++e) {   // S*S <= nslot <= NT*ITEMS
                 const int cell = e * NT + t;
                 if (cell >= S2) continue;
-                const float* p = pimg + cell;
+                const float* p = pimg + cell * cells;
                 if constexpr (kStatic) {
                     float v[C_CT];
 #pragma unroll
@@ -279,7 +287,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                     ccls[cell] = cell_class(logit, 0, C_CT);
                 } else {
                     ccls[cell] = cell_class_mem(
-                        MemLogitsT<kBias>{p, kBias ? a.bias + cell : nullptr, S2}, 5 * nb, nc);
+                        MemLogitsT<kBias>{p, kBias ? a.bias + cell : nullptr, chs}, 5 * nb, nc);
                 }
             }
             group_sync<NT>();
@@ -290,8 +298,8 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                 if (n < nslot) {
                     const int cell = n / nb;
                     const int k = n - cell * nb;
-                    const MemLogitsT<kBias> q{pimg + cell + (5 * k) * S2,
-                                              kBias ? a.bias + cell + (5 * k) * S2 : nullptr, S2};
+                    const MemLogitsT<kBias> q{pimg + cell * cells + (5 * k) * chs,
+                                              kBias ? a.bias + cell + (5 * k) * S2 : nullptr, chs};
                     const float lx = q(0), ly = q(1), lw = q(2), lh = q(3), lc = q(4);
                     cbox[e] = box_from_logits(lx, ly, lw, lh, cell, S, a.cellf, a.imgf);
                     cscore[e] = sigmoidf_(lc);
@@ -847,10 +855,10 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
     YH_STAMP(15);
 }
 
-template <int NT, int ITEMS, int SRC, int S_CT, int BX_CT, int C_CT>
+template <int NT, int ITEMS, int SRC, int S_CT, int BX_CT, int C_CT, bool CM = false>
 __global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    nms_block<NT, ITEMS, SRC, S_CT, BX_CT, C_CT>(a, (int)blockIdx.x, smem);
+    nms_block<NT, ITEMS, SRC, S_CT, BX_CT, C_CT, CM>(a, (int)blockIdx.x, smem);
 }
 
 // ---- candidates to global memory (the values nms_kernel<.,.,0> forms in registers) ---

@@ -98,7 +98,7 @@ int colsum_slices(int64_t nrows) {
     return (int)s;
 }
 
-template <int SRC, int S_CT, int BX_CT, int C_CT>
+template <int SRC, int S_CT, int BX_CT, int C_CT, bool CM = false>
 int launch_nms_shape(yh::NmsArgs a, hipStream_t st) {
 #define YH_NMS_CASE(NT, ITEMS)                                                              \
     {                                                                                       \
@@ -107,7 +107,7 @@ int launch_nms_shape(yh::NmsArgs a, hipStream_t st) {
         const unsigned grid = (unsigned)((a.batch + ipb - 1) / ipb);                        \
         const size_t lds = (size_t)a.region_bytes * ipb;                                    \
         if (lds > kLdsBudget) return YH_ERR_UNSUPPORTED;                                    \
-        hipLaunchKernelGGL((yh::nms_kernel<NT, ITEMS, SRC, S_CT, BX_CT, C_CT>), dim3(grid), \
+        hipLaunchKernelGGL((yh::nms_kernel<NT, ITEMS, SRC, S_CT, BX_CT, C_CT, CM>), dim3(grid), \
                            dim3(yh::NMS_BLOCK), lds, st, a);                                \
         return launch_status();                                                             \
     }
@@ -133,6 +133,8 @@ int launch_nms(const yh::NmsArgs& a, hipStream_t st) {
     if (a.nslot > YH_MAX_CANDIDATES || a.nout > YH_MAX_CANDIDATES) return YH_ERR_UNSUPPORTED;
     if constexpr (SRC == 0) {
         // the two shapes the head is benchmarked on get compile-time channel counts
+        // (channel-major tensors only: their channel offsets are compile-time constants)
+        if (a.cell_major) return launch_nms_shape<0, 0, 0, 0, true>(a, st);
         if (a.S == 7 && a.nb == 2 && a.nc == 20) return launch_nms_shape<0, 7, 2, 20>(a, st);
         if (a.S == 14 && a.nb == 5 && a.nc == 80) return launch_nms_shape<0, 14, 5, 80>(a, st);
     }
@@ -198,8 +200,10 @@ namespace {
 int loss_launch(const float* pred, const float* bias, const float* gt_xywh, const float* gt_cls,
                 const uint8_t* obj_mask, float* grad_pred, float* rows_base, int64_t batch,
                 int S, int Bx, int C, int img_size, float lambda_coord, float lambda_noobj,
-                float inv_global_batch, const yh::LossPipe* pipe, hipStream_t st) {
+                float inv_global_batch, const yh::LossPipe* pipe, hipStream_t st,
+                bool nhwc = false) {
     if (batch > 0 && (!pred || !gt_xywh || !gt_cls || !obj_mask || !grad_pred)) return YH_ERR_NULL;
+    if (nhwc && (bias || pipe)) return YH_ERR_ARG;
     if (!aligned(gt_xywh, 16) || !aligned(pred, 4) || !aligned(grad_pred, 4) ||
         !aligned(gt_cls, 4))
         return YH_ERR_ALIGN;
@@ -211,7 +215,7 @@ int loss_launch(const float* pred, const float* bias, const float* gt_xywh, cons
     const float cellf = (float)(img_size / S);
     const float imgf = (float)img_size;
     if (!aligned(bias, 4)) return YH_ERR_ALIGN;
-    const bool fast = S == 7 && Bx == 2 && C == 20 && aligned(gt_cls, 16) && aligned(grad_pred, 16);
+    const bool fast = !nhwc && S == 7 && Bx == 2 && C == 20 && aligned(gt_cls, 16) && aligned(grad_pred, 16);
     const yh::LossPipe pp = pipe ? *pipe : yh::LossPipe{};
     const dim3 grid((unsigned)(rows + (pipe ? 1 : 0)));
     // run-time shapes: the gradients of a workgroup go through an LDS tile when they fit
@@ -243,7 +247,18 @@ int loss_launch(const float* pred, const float* bias, const float* gt_xywh, cons
         YH_LOSS_GENERIC(PIPE, false, true)                                                       \
     else                                                                                         \
         YH_LOSS_GENERIC(PIPE, false, false)
-    if (pipe) { YH_LOSS_LAUNCH(true) } else { YH_LOSS_LAUNCH(false) }
+    if (nhwc) {
+        if (tile)
+            hipLaunchKernelGGL((yh::loss_fwd_bwd_generic_kernel<false, false, true, true>), grid,
+                               dim3(yh::LOSS_THREADS), lds, st, pred, bias, gt_xywh, gt_cls, obj_mask,
+                               grad_pred, rows_base, (long long)batch, S, Bx, C, g, cellf, imgf,
+                               lambda_coord, lambda_noobj, inv_global_batch, pp);
+        else
+            hipLaunchKernelGGL((yh::loss_fwd_bwd_generic_kernel<false, false, false, true>), grid,
+                               dim3(yh::LOSS_THREADS), lds, st, pred, bias, gt_xywh, gt_cls, obj_mask,
+                               grad_pred, rows_base, (long long)batch, S, Bx, C, g, cellf, imgf,
+                               lambda_coord, lambda_noobj, inv_global_batch, pp);
+    } else if (pipe) { YH_LOSS_LAUNCH(true) } else { YH_LOSS_LAUNCH(false) }
 #undef YH_LOSS_LAUNCH
 #undef YH_LOSS_GENERIC
     return launch_status();
@@ -409,6 +424,24 @@ int yh_loss_fwd_bwd(const float* pred, const float* gt_xywh, const float* gt_cls
     if (const int rc = yh_loss_partials(pred, gt_xywh, gt_cls, obj_mask, grad_pred, workspace,
                                         workspace_bytes, batch, S, Bx, C, img_size, lambda_coord,
                                         lambda_noobj, inv_global_batch, stream))
+        return rc;
+    return yh_loss_finalize(workspace, workspace_bytes, batch, S, inv_global_batch, loss_terms,
+                            nullptr, 0, nullptr, stream);
+}
+
+int yh_loss_fwd_bwd_nhwc(const float* pred, const float* gt_xywh, const float* gt_cls,
+                         const uint8_t* obj_mask, float* grad_pred, float* loss_terms,
+                         void* workspace, size_t workspace_bytes, int64_t batch, int S, int Bx,
+                         int C, int img_size, float lambda_coord, float lambda_noobj,
+                         float inv_global_batch, void* stream) {
+    if (const int rc = check_shape(batch, S, Bx, C, img_size)) return rc;
+    if (!loss_terms) return YH_ERR_NULL;
+    if (!workspace) return YH_ERR_WORKSPACE;
+    if (workspace_bytes < yh_workspace_bytes(YH_OP_LOSS, batch, S, Bx, C)) return YH_ERR_WORKSPACE;
+    if (!aligned(workspace, 16)) return YH_ERR_ALIGN;
+    if (const int rc = loss_launch(pred, nullptr, gt_xywh, gt_cls, obj_mask, grad_pred,
+                                   (float*)workspace, batch, S, Bx, C, img_size, lambda_coord,
+                                   lambda_noobj, inv_global_batch, nullptr, (hipStream_t)stream, true))
         return rc;
     return yh_loss_finalize(workspace, workspace_bytes, batch, S, inv_global_batch, loss_terms,
                             nullptr, 0, nullptr, stream);
@@ -636,7 +669,7 @@ namespace {
 int decode_nms_launch(const float* pred, const float* bias, float* dets, int32_t* keep_count,
                       int32_t* keep_idx, int mode, float conf_thresh, float iou_thresh,
                       int64_t batch, int S, int Bx, int C, int img_size, bool with_bias,
-                      void* stream) {
+                      void* stream, bool nhwc = false) {
     if (const int rc = check_shape(batch, S, Bx, C, img_size)) return rc;
     if (mode != YH_MODE_REFERENCE && mode != YH_MODE_DENSE) return YH_ERR_ARG;
     if (isnan(conf_thresh) || isnan(iou_thresh)) return YH_ERR_ARG;
@@ -655,6 +688,7 @@ int decode_nms_launch(const float* pred, const float* bias, float* dets, int32_t
     a.keep_idx = keep_idx;
     a.batch = batch;
     a.S = S; a.nb = Bx; a.nc = C; a.mode = mode;
+    a.cell_major = nhwc ? 1 : 0;
     a.nslot = mode == YH_MODE_REFERENCE ? S * S : S * S * Bx;
     a.nout = S * S * Bx;
     a.cellf = (float)(img_size / S);
@@ -677,6 +711,13 @@ int yh_decode_nms(const float* pred, float* dets, int32_t* keep_count, int32_t* 
                   int C, int img_size, void* stream) {
     return decode_nms_launch(pred, nullptr, dets, keep_count, keep_idx, mode, conf_thresh,
                              iou_thresh, batch, S, Bx, C, img_size, false, stream);
+}
+
+int yh_decode_nms_nhwc(const float* pred, float* dets, int32_t* keep_count, int32_t* keep_idx,
+                       int mode, float conf_thresh, float iou_thresh, int64_t batch, int S, int Bx,
+                       int C, int img_size, void* stream) {
+    return decode_nms_launch(pred, nullptr, dets, keep_count, keep_idx, mode, conf_thresh,
+                             iou_thresh, batch, S, Bx, C, img_size, false, stream, true);
 }
 
 int yh_decode_nms_linear(const float* z, const float* bias, float* dets, int32_t* keep_count,

@@ -191,13 +191,27 @@ class YOLOv1Head(nn.Module):
         out = self.backbone(x) if self.backbone is not None else x
         return out.view(-1, self.depth, self.n_cells, self.n_cells)
 
-    def _check_out(self, out: torch.Tensor) -> torch.Tensor:
+    def _check_out(self, out: torch.Tensor, allow_channels_last: bool = False) -> torch.Tensor:
         if not isinstance(out, torch.Tensor):
             raise TypeError(f"out: expected a torch.Tensor, got {type(out).__name__}")
         if out.dim() != 4 or tuple(out.shape[1:]) != (self.depth, self.n_cells, self.n_cells):
             raise ValueError(f"out: expected shape (B, {self.depth}, {self.n_cells}, "
                              f"{self.n_cells}), got {tuple(out.shape)}")
+        if allow_channels_last and self._cell_major(out):
+            if not out.is_cuda:
+                raise ValueError(f"out: must live on the GPU (got device {out.device}); yolo_amd has no CPU path")
+            if out.dtype != torch.float32:
+                raise ValueError(f"out: expected dtype torch.float32, got {out.dtype}")
+            return out
         return _need(out, "out", torch.float32)
+
+    @staticmethod
+    def _cell_major(out: torch.Tensor) -> bool:
+        """A (B, D, S, S) tensor in channels-last memory format: its storage is
+        (B, S, S, D), a cell's D values consecutive -- what a backbone that ends in a
+        channels-last convolution emits.  The loss and postprocess read it in place
+        (yh_loss_fwd_bwd_nhwc, yh_decode_nms_nhwc); the gradient comes back in the same format."""
+        return (not out.is_contiguous()) and out.is_contiguous(memory_format=torch.channels_last)
 
     def _check_bias(self, bias: torch.Tensor, device) -> torch.Tensor:
         bias = _need(bias.detach(), "bias", torch.float32)
@@ -220,7 +234,11 @@ class YOLOv1Head(nn.Module):
     # --------------------------------------------------------------------- loss
     def _launch_loss(self, out, gt_norm_xywh, gt_cls_prob, obj_mask, inv_global_batch, log=None,
                      finalize_stream=None):
-        out = self._check_out(out)
+        out = self._check_out(out, allow_channels_last=True)
+        nhwc = self._cell_major(out)
+        if nhwc and (log is not None or finalize_stream is not None):
+            raise ValueError("out: a channels-last head tensor goes through the plain loss call only "
+                             "(no device-side log, no side-stream finalize)")
         bsz, n = out.shape[0], self.n_grid
         _need(gt_norm_xywh, "gt_norm_xywh", torch.float32, (bsz, n, 1, 4))
         _need(gt_cls_prob, "gt_cls_prob", torch.float32, (bsz, n, 1, self.n_classes))
@@ -246,7 +264,8 @@ class YOLOv1Head(nn.Module):
                 # a finalize on a side stream may still be reading the shared workspace
                 torch.cuda.current_stream(out.device).wait_event(pending)
             if log is None and finalize_stream is None:
-                _lib.check(lib.yh_loss_fwd_bwd(
+                fn = lib.yh_loss_fwd_bwd_nhwc if nhwc else lib.yh_loss_fwd_bwd
+                _lib.check(fn(
                     out.data_ptr(), gt_norm_xywh.data_ptr(), gt_cls_prob.data_ptr(),
                     obj_mask.data_ptr(), grad.data_ptr(), terms.data_ptr(), ws.data_ptr(),
                     ws.numel(), bsz, self.n_cells, self.n_bboxes, self.n_classes, self.img_size,
@@ -618,8 +637,12 @@ class YOLOv1Head(nn.Module):
         confidence descending) and zero rows after them, keep_count (B,) int32,
         and with ``return_idx`` keep_idx (B, S*S*Bx) int32 (flat index
         cell*Bx + k of each kept row, -1 padding)."""
-        out = self._check_out(out.detach())
+        out = self._check_out(out.detach(), allow_channels_last=True)
+        nhwc = self._cell_major(out)
         bsz, nn_, dev = out.shape[0], self.n_grid * self.n_bboxes, out.device
+        if nhwc and (bias is not None or nn_ > _lib.YH_MAX_CANDIDATES):
+            raise ValueError("out: a channels-last head tensor is read in place only without a bias and "
+                             f"up to {_lib.YH_MAX_CANDIDATES} candidates per image; pass out.contiguous()")
         dets = torch.empty(bsz, nn_, 6, dtype=torch.float32, device=dev)
         count = torch.empty(bsz, dtype=torch.int32, device=dev)
         kidx = torch.empty(bsz, nn_, dtype=torch.int32, device=dev) if return_idx else None
@@ -635,6 +658,8 @@ class YOLOv1Head(nn.Module):
                                  device=dev)
                 _lib.check(lib.yh_decode_nms_ws(out.data_ptr(), _ptr(bias), *tail, ws.data_ptr(),
                                                 ws.numel(), _stream(dev)))
+            elif nhwc:
+                _lib.check(lib.yh_decode_nms_nhwc(out.data_ptr(), *tail, _stream(dev)))
             elif bias is None:
                 _lib.check(lib.yh_decode_nms(out.data_ptr(), *tail, _stream(dev)))
             else:
