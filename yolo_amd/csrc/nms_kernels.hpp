@@ -51,6 +51,7 @@ struct NmsArgs {
     int nout;   // rows of dets per image
     float cellf, imgf, conf_thr, iou_thr;
     // per-image LDS region: byte offsets of the arrays inside it, and its size
+    int off_stage;   // cell-major only: LDS copy of the image's block (-1: read from memory)
     int off_keys, off_box, off_meta, off_seg, off_alive, off_misc, off_ccls, off_hist, off_segst, off_pair, off_kill;
     int region_bytes;
     int dbg_stop;  // builds with -DYH_PHASE_PROBE only: leave after this phase (0 = run everything)
@@ -216,10 +217,22 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         const int nc = kStatic ? C_CT : a.nc;
         const long long D = 5 * nb + nc;
         const float* pimg = a.pred + img * D * S2;
-        // floats between two channels of a cell and between two cells of a channel; with
-        // CM the channel stride is the constant 1, so a lane's loads can be merged
+        // floats between two channels of a cell and between two cells of a channel
         const int chs = CM ? 1 : S2;
         const int cells = CM ? (int)D : 1;
+        if constexpr (CM) {
+            // A lane's cell is D floats away from its neighbour's: read from memory cell by
+            // cell, a wavefront load would touch a line per lane.  The image's block comes in
+            // through LDS in consecutive 4-byte loads instead (when the host found room for
+            // it) and the lanes pick their cells up from there.
+            if (a.off_stage >= 0) {
+                float* stage = reinterpret_cast<float*>(region + a.off_stage);
+                const int nfl = (int)D * S2;
+                for (int i = t; i < nfl; i += NT) stage[i] = pimg[i];
+                group_sync<NT>();
+                pimg = stage;
+            }
+        }
         if (a.mode == 0) {
             // slot = cell; the higher-confidence predictor is the candidate
 #pragma unroll

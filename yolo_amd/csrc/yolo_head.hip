@@ -65,7 +65,7 @@ inline unsigned grid_for(int64_t n) {
 }
 
 // LDS layout of one image's region in nms_kernel
-void nms_layout(yh::NmsArgs& a, int slot_pad) {
+void nms_layout(yh::NmsArgs& a, int slot_pad, int imgs_per_block = 1) {
     a.off_keys = 0;
     a.off_box = slot_pad * 8;
     a.off_meta = slot_pad * 24;
@@ -87,6 +87,14 @@ void nms_layout(yh::NmsArgs& a, int slot_pad) {
     // kill and precedence tables of the one-wavefront path: 2 x 64 words of 64 bits
     a.off_kill = off;
     off += 1024;
+    // a cell-major image is staged through LDS when the blocks of a workgroup's images are
+    // small enough to leave room for a second workgroup on the CU
+    a.off_stage = -1;
+    const int block_bytes = (5 * a.nb + a.nc) * a.S * a.S * 4;
+    if (a.cell_major && (long long)block_bytes * imgs_per_block <= 48 * 1024) {
+        a.off_stage = off;
+        off += round16(block_bytes);
+    }
     a.region_bytes = off;
 }
 
@@ -102,7 +110,7 @@ template <int SRC, int S_CT, int BX_CT, int C_CT, bool CM = false>
 int launch_nms_shape(yh::NmsArgs a, hipStream_t st) {
 #define YH_NMS_CASE(NT, ITEMS)                                                              \
     {                                                                                       \
-        nms_layout(a, NT * ITEMS);                                                          \
+        nms_layout(a, NT * ITEMS, yh::NMS_BLOCK / NT);                                      \
         const int ipb = yh::NMS_BLOCK / NT;                                                 \
         const unsigned grid = (unsigned)((a.batch + ipb - 1) / ipb);                        \
         const size_t lds = (size_t)a.region_bytes * ipb;                                    \
