@@ -35,8 +35,11 @@ lt, lb, ct = (t.to(dev) for t in synth.make_gt_boxes(B, seed=1))
 lb = lb.to(torch.int32); ct = ct.to(torch.int32)
 ex = torch.empty(B, 49, 1, 4, device=dev); ec = torch.empty(B, 49, 1, 20, device=dev); em = torch.empty(B, 49, 1, 1, dtype=torch.uint8, device=dev)
 def k_enc(): lib.yh_encode_targets(lt.data_ptr(), lb.data_ptr(), ct.data_ptr(), ex.data_ptr(), ec.data_ptr(), em.data_ptr(), B, lt.shape[1], 7, 20, 448, st)
+def k_encloss():
+    k_enc()
+    lib.yh_loss_partials(pred.data_ptr(), ex.data_ptr(), ec.data_ptr(), em.data_ptr(), grad.data_ptr(), ws.data_ptr(), ws.numel(), B, 7, 2, 20, 448, 5.0, 0.5, 1.0 / B, st)
 which = sys.argv[1:] or ["loss", "fin", "nms"]
 out = []
 for w in which:
-    out.append("%s %.2f us" % (w, b2b({"loss": k_loss, "pipe": k_pipe, "two": k_two, "fin": k_fin, "nms": k_nms, "enc": k_enc}[w])))
+    out.append("%s %.2f us" % (w, b2b({"loss": k_loss, "pipe": k_pipe, "two": k_two, "fin": k_fin, "nms": k_nms, "enc": k_enc, "encloss": k_encloss}[w])))
 print(os.environ.get("KB_TAG", ""), " | ".join(out))

@@ -103,9 +103,9 @@ __global__ __launch_bounds__(256) void encode_targets_tiled_kernel(
             const int f = q * 4;
             const int item = f / C, j = f - item * C;
             const int lab = w_label[item];
-            reinterpret_cast<float4*>(rows)[q] =
-                make_float4(lab == j ? 1.f : 0.f, lab == j + 1 ? 1.f : 0.f,
-                            lab == j + 2 ? 1.f : 0.f, lab == j + 3 ? 1.f : 0.f);
+            store_stream(reinterpret_cast<float4*>(rows) + q,
+                         make_float4(lab == j ? 1.f : 0.f, lab == j + 1 ? 1.f : 0.f,
+                                     lab == j + 2 ? 1.f : 0.f, lab == j + 3 ? 1.f : 0.f));
         }
     } else {
         for (int f = threadIdx.x; f < nfl; f += 256) {
