@@ -645,7 +645,8 @@ def stress_record(args, torch, dev, st):
     torch.cuda.synchronize()
     out["decode_nms_algorithmic_bytes_per_launch"] = nms_algo
     out["loss_algorithmic_bytes_per_launch"] = loss_algo
-    out["loss_note"] = "two launches (gradient kernel + finalize), run-time-shape kernel"
+    out["loss_note"] = ("two launches (gradient kernel + finalize); run-time shape, the 82 KB image block leaves "
+                        "through a rolling LDS window in non-temporal stores (loss_fwd_bwd_roll_kernel)")
     out["kept_per_image"] = float(sets[0]["cnt"].float().mean().item())
     return out
 

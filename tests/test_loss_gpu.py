@@ -494,6 +494,46 @@ def test_pipelined_other_shape_and_errors(dev):
     torch.cuda.synchronize()
 
 
+def test_large_blocks_leave_through_a_rolling_window(dev):
+    """A workgroup's block too large for the LDS tile (S=14, Bx=5, C=80: 82 KB per image)
+    leaves in 16-byte stores through a window of LDS; the object cells' gradients wait
+    in a few LDS rows (19 at this shape) and a workgroup with more object cells than
+    that stores directly.  Images with 0, 1, 19, 20 and 196 object cells side by side,
+    channel-major and channels-last, on a gradient buffer at every 4-byte offset."""
+    from yolo_amd import _lib
+    lib = _lib.load()
+    S, Bx, C, img = 14, 5, 80, 448
+    head = YOLOv1Head(img_size=img, n_cells=S, n_bboxes=Bx, n_classes=C)
+    counts = [0, 1, 19, 20, 196, 7, 18, 21]
+    batch = len(counts)
+    g = torch.Generator().manual_seed(14)
+    pred = synth.make_pred(batch, S, Bx, C, seed=3)
+    gx = torch.rand(batch, S * S, 1, 4, generator=g) * 0.9 + 0.05
+    gc = torch.softmax(torch.randn(batch, S * S, 1, C, generator=g) * 3, dim=-1)
+    om = torch.zeros(batch, S * S, 1, 1, dtype=torch.bool)
+    for b, n in enumerate(counts):
+        om[b, torch.randperm(S * S, generator=g)[:n]] = True
+    gx, gc = gx * om, gc * om
+    ref = ref_cpu.loss_and_grad(pred, gx, gc, om, **hp_of(head))
+    terms, grad = run_hip(head, dev, pred, gx, gc, om)
+    check_against_oracle(terms, grad, ref)
+    terms_cl, grad_cl = head.loss_fwd_bwd(pred.to(dev).contiguous(memory_format=torch.channels_last),
+                                          gx.to(dev), gc.to(dev), om.to(dev))
+    assert torch.equal(terms_cl.cpu(), terms) and torch.equal(grad_cl.cpu().contiguous(), grad)
+    d = [t.to(dev) for t in (pred, gx, gc, om.view(torch.uint8))]
+    ws = torch.empty(lib.yh_workspace_bytes(_lib.YH_OP_LOSS, batch, S, Bx, C), dtype=torch.uint8, device=dev)
+    for shift in (1, 2, 3):
+        buf = torch.full((pred.numel() + 8,), float("nan"), device=dev)
+        gview = buf[shift:shift + pred.numel()]
+        t5 = torch.empty(5, device=dev)
+        _lib.check(lib.yh_loss_fwd_bwd(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
+                                       gview.data_ptr(), t5.data_ptr(), ws.data_ptr(), ws.numel(), batch, S,
+                                       Bx, C, img, 5.0, 0.5, 1.0 / batch, torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert torch.isnan(buf[:shift]).all() and torch.isnan(buf[shift + pred.numel():]).all()
+        assert torch.equal(gview.cpu().view_as(grad), grad) and torch.equal(t5.cpu(), terms)
+
+
 @pytest.mark.parametrize("S,Bx,C", [(7, 2, 20), (7, 3, 20), (13, 5, 20)])
 def test_gradient_buffer_not_16_byte_aligned(dev, S, Bx, C):
     """The kernels that collect a workgroup's gradients in LDS store them in 16-byte

@@ -682,6 +682,211 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_generic_kernel(
     }
 }
 
+// Run-time shape, channel-major, a workgroup's block too large for the LDS tile (S=14,
+// Bx=5, C=80: 82 KB per image).  Storing the gradients lane by lane leaves them as
+// 4-byte pieces in rows of S*S floats that end anywhere in a cache line; here the block
+// still leaves in 16-byte non-temporal stores, LOSS_ROLL_FLOATS of it at a time.  What a
+// piece of the block holds is known without a tile of the whole block: zeros, except the
+// confidence gradients of the cells without an object (kept per cell and predictor in
+// LDS, `cg`) and the D gradients of each cell with one (`og`, one row per listed cell,
+// written by pass 2 with a channel stride of 1).  Per piece: zero the window, drop the
+// confidence values and the object cells' values that fall into it (every thread
+// holds the block offsets of its few entries in registers), store.  A workgroup with
+// more object cells than `og` has rows for stores everything directly instead.
+constexpr int LOSS_ROLL_FLOATS = 4096;          // the window: 16 KB
+constexpr int LOSS_ROLL_ENTRIES = 8;            // conf / object entries a thread holds
+constexpr int LOSS_ROLL_CAP_FLOATS = LOSS_ROLL_ENTRIES * LOSS_THREADS;   // of cg, and of og
+constexpr unsigned int LOSS_ROLL_SKIP = 0x7FC0DEADu;   // cg entry of a cell that holds an object
+
+template <bool BIAS, bool NHWC = false>
+__global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_roll_kernel(
+    const float* __restrict__ pred, const float* __restrict__ bias,
+    const float* __restrict__ gt_xywh, const float* __restrict__ gt_cls,
+    const uint8_t* __restrict__ obj_mask, float* __restrict__ grad, float* __restrict__ partials,
+    long long batch, int S, int nb, int nc, int imgs_per_block, float cellf, float imgf, float lc,
+    float ln, float inv_gb, int og_cap) {
+    const int bid = blockIdx.x;
+    const int S2 = S * S;
+    const int D = 5 * nb + nc;
+    const int DS2 = D * S2;
+    // floats between two channels of a cell and between two cells of a channel (NHWC: the
+    // block is cell-major, see loss_fwd_bwd_generic_kernel)
+    const int chs = NHWC ? 1 : S2;
+    const int cls_ = NHWC ? D : 1;
+    const long long img0 = (long long)bid * imgs_per_block;
+    const int nitems = imgs_per_block * S2;      // * nb <= LOSS_ROLL_CAP_FLOATS (the host checks)
+    constexpr int NW = LOSS_THREADS / 64;
+    constexpr int LIST_CAP = 4096 / NW;
+    __shared__ unsigned short olist[NW][LIST_CAP];
+    __shared__ int wcount[NW];
+    extern __shared__ __attribute__((aligned(16))) float rollmem[];
+    float* win = rollmem;                                   // LOSS_ROLL_FLOATS
+    float* og = win + LOSS_ROLL_FLOATS;                     // og_cap * D
+    float* cg = og + (size_t)og_cap * D;                    // nitems * nb
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc_coord = 0.f, acc_conf = 0.f, acc_cls = 0.f;
+    int listed = 0;
+    // pass 1: the confidence gradients of the cells without an object; the others are listed
+    for (int item0 = 0; item0 < nitems; item0 += LOSS_THREADS) {
+        const int item = item0 + threadIdx.x;
+        bool has_obj = false;
+        if (item < nitems) {
+            const int gi = item / S2;
+            const int cell = item - gi * S2;
+            const long long img = img0 + gi;
+            if (img < batch) {
+                has_obj = obj_mask[img * S2 + cell] != 0;
+                float* c = cg + (size_t)item * nb;
+                if (!has_obj) {
+                    const GlobalLogits<BIAS> logit{pred + img * (long long)DS2 + cell * cls_,
+                                                   BIAS ? bias + cell : nullptr, chs};
+                    for (int k0 = 0; k0 < nb; k0 += 4) {
+                        float v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = k0 + u < nb ? logit(5 * (k0 + u) + 4) : 0.0f;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (k0 + u < nb) {
+                                const float conf = sigmoidf_(v[u]);
+                                acc_conf += ln * (conf * conf);
+                                c[k0 + u] = 2.0f * ln * conf * (conf * (1.0f - conf)) * inv_gb;
+                            }
+                        }
+                    }
+                } else {
+                    for (int k = 0; k < nb; ++k) c[k] = __uint_as_float(LOSS_ROLL_SKIP);
+                }
+            }
+        }
+        const unsigned long long om = __ballot(has_obj);
+        if (has_obj)
+            olist[wave][listed + __popcll(om & ((1ull << lane) - 1ull))] = (unsigned short)item;
+        listed += __popcll(om);
+    }
+    if (lane == 0) wcount[wave] = listed;
+    __syncthreads();
+    int cnt[NW];
+    int total_obj = 0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) { cnt[q] = wcount[q]; total_obj += cnt[q]; }
+    const bool direct = total_obj > og_cap;      // the same for the whole workgroup
+    auto listed_item = [&](int j0) -> int {
+        int j = j0, src = 0;
+#pragma unroll
+        for (int q = 0; q < NW - 1; ++q)
+            if (src == q && j >= cnt[q]) { j -= cnt[q]; src = q + 1; }
+        return olist[src][j];
+    };
+    if (direct) {
+        // every cell's D values straight to memory first (zeros and the confidence
+        // gradients; an object cell gets zeros here and its values from pass 2 below)
+        for (int item = threadIdx.x; item < nitems; item += LOSS_THREADS) {
+            const int gi = item / S2;
+            const int cell = item - gi * S2;
+            if (img0 + gi < batch) {
+                float* g = grad + (img0 + gi) * (long long)DS2 + cell * cls_;
+                const float* c = cg + (size_t)item * nb;
+                for (int ch = 0; ch < D; ++ch) {
+                    float v = 0.0f;
+                    if (ch < 5 * nb && ch % 5 == 4) {
+                        v = c[ch / 5];
+                        if (__float_as_uint(v) == LOSS_ROLL_SKIP) v = 0.0f;
+                    }
+                    g[(size_t)ch * chs] = v;
+                }
+            }
+        }
+        __syncthreads();     // those stores are performed before pass 2 stores to the same words
+    }
+    // pass 2: the listed cells, a group of lanes per cell
+    auto listed_cell = [&](int j0, auto gw) {
+        constexpr int GW = decltype(gw)::value;
+        const int item = listed_item(j0);
+        const int gi = item / S2;
+        const int cell = item - gi * S2;
+        const long long img = img0 + gi;
+        const long long tcell = img * S2 + cell;
+        const long long off = img * (long long)DS2 + cell * cls_;
+        const GlobalLogits<BIAS> logit{pred + off, BIAS ? bias + cell : nullptr, chs};
+        float* g = direct ? grad + off : og + (size_t)j0 * D;
+        loss_obj_cell_wave<GW>(logit, g, gt_xywh + tcell * 4, gt_cls + tcell * nc, cell, S,
+                               direct ? chs : 1, nb, nc, cellf, imgf, lc, ln, inv_gb, acc_coord,
+                               acc_conf, acc_cls);
+    };
+    if (nc <= 64) {
+        for (int j0 = (int)threadIdx.x / 16; j0 < total_obj; j0 += LOSS_THREADS / 16)
+            listed_cell(j0, std::integral_constant<int, 16>{});
+    } else if (nc <= 128) {
+        for (int j0 = (int)threadIdx.x / 32; j0 < total_obj; j0 += LOSS_THREADS / 32)
+            listed_cell(j0, std::integral_constant<int, 32>{});
+    } else {
+        for (int j0 = wave; j0 < total_obj; j0 += NW)
+            listed_cell(j0, std::integral_constant<int, 64>{});
+    }
+    loss_block_reduce(acc_coord, acc_conf, acc_cls, partials, bid);   // has a barrier after the LDS writes
+    if (direct) return;
+    // ---- the block leaves, a window at a time
+    const long long gbase = img0 * (long long)DS2;
+    const long long left = batch - img0;
+    const int n = (int)(left < imgs_per_block ? left : imgs_per_block) * DS2;   // floats of this block
+    float* gout = grad + gbase;
+    // block offsets and values of this thread's entries: confidence gradients ...
+    int ce[LOSS_ROLL_ENTRIES], oe[LOSS_ROLL_ENTRIES];
+    float cv[LOSS_ROLL_ENTRIES], ov[LOSS_ROLL_ENTRIES];
+#pragma unroll
+    for (int u = 0; u < LOSS_ROLL_ENTRIES; ++u) {
+        const int q = u * LOSS_THREADS + (int)threadIdx.x;
+        ce[u] = -1; cv[u] = 0.f; oe[u] = -1; ov[u] = 0.f;
+        if (q < nitems * nb) {
+            const int item = q / nb, k = q - item * nb;
+            const int gi = item / S2, cell = item - gi * S2;
+            const float v = cg[q];
+            if (img0 + gi < batch && __float_as_uint(v) != LOSS_ROLL_SKIP) {
+                ce[u] = gi * DS2 + (5 * k + 4) * chs + cell * cls_;
+                cv[u] = v;
+            }
+        }
+        // ... and the values of the object cells
+        if (q < total_obj * D) {
+            const int j0 = q / D, ch = q - j0 * D;
+            const int item = listed_item(j0);
+            const int gi = item / S2, cell = item - gi * S2;
+            oe[u] = gi * DS2 + ch * chs + cell * cls_;
+            ov[u] = og[q];
+        }
+    }
+    const int pad = (int)(gbase & 3);
+    const int head = n < ((4 - pad) & 3) ? n : ((4 - pad) & 3);   // floats up to the 16-byte grid
+    const int body = ((n - head) >> 2) << 2;                      // floats that leave as float4
+    // one window [c0, c0 + len) of the block: zero, drop the entries in, store
+    // The barriers between the steps order LDS accesses only.  __syncthreads() would also
+    // wait for the window's global stores to be acknowledged -- a trip to HBM per window.
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto window = [&](int c0, int len, bool vec) {
+        lds_barrier();                                            // the last window has been read
+        for (int i = threadIdx.x; i < (len + 3) / 4; i += LOSS_THREADS)
+            reinterpret_cast<float4*>(win)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        lds_barrier();
+#pragma unroll
+        for (int u = 0; u < LOSS_ROLL_ENTRIES; ++u) {
+            if (ce[u] >= c0 && ce[u] < c0 + len) win[ce[u] - c0] = cv[u];
+            if (oe[u] >= c0 && oe[u] < c0 + len) win[oe[u] - c0] = ov[u];
+        }
+        lds_barrier();
+        if (vec) {
+            float4* g4 = reinterpret_cast<float4*>(gout + c0);
+            for (int i = threadIdx.x; i < len / 4; i += LOSS_THREADS)
+                store_stream(g4 + i, reinterpret_cast<const float4*>(win)[i]);
+        } else {
+            if ((int)threadIdx.x < len) gout[c0 + threadIdx.x] = win[threadIdx.x];
+        }
+    };
+    if (head > 0) window(0, head, false);
+    for (int c0 = head; c0 < head + body; c0 += LOSS_ROLL_FLOATS)
+        window(c0, head + body - c0 < LOSS_ROLL_FLOATS ? head + body - c0 : LOSS_ROLL_FLOATS, true);
+    if (n - head - body > 0) window(head + body, n - head - body, false);
+}
+
 // Compile-time shape.  A lane keeps the logits it needs in registers; with S*S
 // known, every channel of a cell is a constant byte offset from the cell's
 // address (no per-channel address arithmetic).
