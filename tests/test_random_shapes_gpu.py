@@ -58,6 +58,15 @@ def test_random_configuration(dev, S, Bx, C, batch, mode, ct, it, seed):
                              present.cpu().numpy(), ct, it)
     for g_, w in zip(got, want):
         np.testing.assert_array_equal(g_.cpu().numpy().view(np.uint32), np.asarray(w).view(np.uint32))
+    # the same tensor in channels-last memory format (cell-major) is read in place: same
+    # bits from the run-time-shape kernels, the same rows from decode + NMS
+    pcl = pred.to(dev).contiguous(memory_format=torch.channels_last)
+    terms_cl, grad_cl = head.loss_fwd_bwd(pcl, gx.to(dev), gc.to(dev), om.to(dev))
+    if (S, Bx, C) != (7, 2, 20):
+        assert torch.equal(terms_cl, terms) and torch.equal(grad_cl.contiguous(), grad)
+    if S * S * Bx <= 2048:
+        for g_, w in zip(head.postprocess(pcl, ct, it, mode, return_idx=True), got):
+            assert torch.equal(g_, w)
     got2 = YOLOv1Head.nms(ltrb, score, cls, present, ct, it, return_idx=True)
     for g_, w in zip(got2, want):
         np.testing.assert_array_equal(g_.cpu().numpy().view(np.uint32), np.asarray(w).view(np.uint32))
