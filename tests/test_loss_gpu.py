@@ -532,6 +532,23 @@ def test_large_blocks_leave_through_a_rolling_window(dev):
         torch.cuda.synchronize()
         assert torch.isnan(buf[:shift]).all() and torch.isnan(buf[shift + pred.numel():]).all()
         assert torch.equal(gview.cpu().view_as(grad), grad) and torch.equal(t5.cpu(), terms)
+    # the pipelined step (one launch, the sums logged one call late) and the bias-fused
+    # entry point take the same kernel: same gradient bits, same logged sums
+    from yolo_amd import LossLog
+    log, ref_log = LossLog(dev, 4), LossLog(dev, 4)
+    dd = [t.to(dev) for t in (pred, gx, gc, om)]
+    for _ in range(2):
+        gp = head.loss_step_pipelined(*dd, log)
+        head.loss_fwd_bwd(*dd, log=ref_log)
+        assert torch.equal(gp.cpu(), grad)
+    head.flush_loss_log(log)
+    torch.cuda.synchronize()
+    assert torch.equal(log.ring, ref_log.ring) and int(log.cursor) == 2
+    bias = torch.randn(pred[0].numel(), generator=g)
+    z = (pred - bias.view(1, -1, S, S)).reshape(batch, -1)
+    tl, gz, gb = head.loss_fwd_bwd_linear(z.to(dev), bias.to(dev), *dd[1:])
+    ref_b = ref_cpu.loss_and_grad(z.view_as(pred) + bias.view(1, -1, S, S), gx, gc, om, **hp_of(head))
+    check_against_oracle(tl.cpu(), gz.cpu().view_as(pred), ref_b)
 
 
 @pytest.mark.parametrize("S,Bx,C", [(7, 2, 20), (7, 3, 20), (13, 5, 20)])

@@ -698,14 +698,22 @@ constexpr int LOSS_ROLL_ENTRIES = 8;            // conf / object entries a threa
 constexpr int LOSS_ROLL_CAP_FLOATS = LOSS_ROLL_ENTRIES * LOSS_THREADS;   // of cg, and of og
 constexpr unsigned int LOSS_ROLL_SKIP = 0x7FC0DEADu;   // cg entry of a cell that holds an object
 
-template <bool BIAS, bool NHWC = false>
+template <bool BIAS, bool NHWC = false, bool PIPE = false>
 __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_roll_kernel(
     const float* __restrict__ pred, const float* __restrict__ bias,
     const float* __restrict__ gt_xywh, const float* __restrict__ gt_cls,
     const uint8_t* __restrict__ obj_mask, float* __restrict__ grad, float* __restrict__ partials,
     long long batch, int S, int nb, int nc, int imgs_per_block, float cellf, float imgf, float lc,
-    float ln, float inv_gb, int og_cap) {
-    const int bid = blockIdx.x;
+    float ln, float inv_gb, int og_cap, LossPipe pipe) {
+    int bid = blockIdx.x;
+    if constexpr (PIPE) {
+        // workgroup 0 logs the previous call, the others are this call's row 0, 1, ...
+        if (bid == 0) {
+            loss_pipe_log(pipe, (int)gridDim.x - 1, inv_gb);
+            return;
+        }
+        --bid;
+    }
     const int S2 = S * S;
     const int D = 5 * nb + nc;
     const int DS2 = D * S2;

@@ -259,25 +259,21 @@ int loss_launch(const float* pred, const float* bias, const float* gt_xywh, cons
     // share of the per-cell confidence gradients and of the object cells' rows fits its registers
     const int D = 5 * Bx + C;
     const int og_cap = yh::LOSS_ROLL_CAP_FLOATS / D;
-    const bool roll = !fast && !tile && !pipe && og_cap >= 4 &&
+    const bool roll = !fast && !tile && og_cap >= 4 &&
                       (long long)g * S * S * Bx <= yh::LOSS_ROLL_CAP_FLOATS;
     if (roll) {
         const size_t roll_lds = ((size_t)yh::LOSS_ROLL_FLOATS + (size_t)og_cap * D + (size_t)g * S * S * Bx) * 4;
-        if (nhwc)
-            hipLaunchKernelGGL((yh::loss_fwd_bwd_roll_kernel<false, true>), grid, dim3(yh::LOSS_THREADS),
-                               roll_lds, st, pred, bias, gt_xywh, gt_cls, obj_mask, grad_pred, rows_base,
-                               (long long)batch, S, Bx, C, g, cellf, imgf, lambda_coord, lambda_noobj,
-                               inv_global_batch, og_cap);
-        else if (bias)
-            hipLaunchKernelGGL((yh::loss_fwd_bwd_roll_kernel<true>), grid, dim3(yh::LOSS_THREADS), roll_lds,
-                               st, pred, bias, gt_xywh, gt_cls, obj_mask, grad_pred, rows_base,
-                               (long long)batch, S, Bx, C, g, cellf, imgf, lambda_coord, lambda_noobj,
-                               inv_global_batch, og_cap);
-        else
-            hipLaunchKernelGGL((yh::loss_fwd_bwd_roll_kernel<false>), grid, dim3(yh::LOSS_THREADS), roll_lds,
-                               st, pred, bias, gt_xywh, gt_cls, obj_mask, grad_pred, rows_base,
-                               (long long)batch, S, Bx, C, g, cellf, imgf, lambda_coord, lambda_noobj,
-                               inv_global_batch, og_cap);
+#define YH_LOSS_ROLL(BIAS, NHWC, PIPE)                                                              \
+        hipLaunchKernelGGL((yh::loss_fwd_bwd_roll_kernel<BIAS, NHWC, PIPE>), grid, dim3(yh::LOSS_THREADS), \
+                           roll_lds, st, pred, bias, gt_xywh, gt_cls, obj_mask, grad_pred, rows_base,  \
+                           (long long)batch, S, Bx, C, g, cellf, imgf, lambda_coord, lambda_noobj,     \
+                           inv_global_batch, og_cap, pp);
+        if (nhwc) YH_LOSS_ROLL(false, true, false)
+        else if (bias && pipe) YH_LOSS_ROLL(true, false, true)
+        else if (bias) YH_LOSS_ROLL(true, false, false)
+        else if (pipe) YH_LOSS_ROLL(false, false, true)
+        else YH_LOSS_ROLL(false, false, false)
+#undef YH_LOSS_ROLL
     } else if (nhwc) {
         if (tile)
             hipLaunchKernelGGL((yh::loss_fwd_bwd_generic_kernel<false, false, true, true>), grid,
