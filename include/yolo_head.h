@@ -103,7 +103,7 @@ int yh_loss_fwd_bwd(const float* pred, const float* gt_xywh, const float* gt_cls
  * its device address is looked up once per device, on the first call made with
  * that device current.  Same kernels and same bits as yh_loss_fwd_bwd.
  * Limit: yh_workspace_bytes(YH_OP_LOSS, batch, S, Bx, C) <= YH_STATIC_SCRATCH_BYTES
- * (batch <= 81,920 at S = 7; batch <= 16,384 for S >= 16), else YH_ERR_SCRATCH.
+ * (batch <= 65,536 at S = 7; batch <= 16,384 for S >= 12), else YH_ERR_SCRATCH.
  * All calls on one GPU share that GPU's array: calls that overlap there (two
  * streams, two threads) race on the rows; order them.  Nothing in the array has
  * to start at zero -- a call writes every row it later reads.

@@ -15,7 +15,7 @@ base = synth.make_inputs(B)
 def make():
     pred, gx, gc, om = (t.to(dev).clone() for t in base)
     return pred, gx, gc, om.view(torch.uint8), torch.empty_like(pred)
-nblk = (B + 4) // 5
+nblk = (B + 3) // 4
 stamps = torch.zeros(nblk, 8, dtype=torch.int64, device=dev)
 names = ["entry", "pass 1 (mask, logits in; no-object cells done)", "barrier", "pass 2 (object cells)",
          "block sums", "tile stored (issued)"]

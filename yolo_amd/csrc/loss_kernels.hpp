@@ -19,6 +19,12 @@
 namespace yh {
 
 constexpr int LOSS_THREADS = 256;
+// Images per workgroup for a grid of S2 cells (one lane per cell).  As many as fit the
+// workgroup -- except at S = 7, where four (196 of 256 lanes) beat five: a batch of
+// 4096 is then 1024 workgroups, four on every CU, where 820 leave a fifth of the CUs
+// with one workgroup more than the rest, and the launch waits for those (12.0 -> 11.2 us
+// over rotating buffers; three: 14.0, two: 14.2).
+constexpr int loss_ipb_for(int S2) { return S2 == 49 ? 4 : LOSS_THREADS / S2; }
 
 #ifdef YH_PHASE_PROBE
 // probe builds only: eight time stamps per workgroup (100 MHz counter) of loss_block
@@ -902,7 +908,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_roll_kernel(
 // LDS floats of the gradient tile of one workgroup
 template <int S, int BX, int C>
 constexpr int loss_tile_floats() {
-    return (LOSS_THREADS / (S * S)) * (5 * BX + C) * S * S + 4;
+    return loss_ipb_for(S * S) * (5 * BX + C) * S * S + 4;
 }
 
 // The work of workgroup `bid` of a grid of `nblocks` (with PIPE, workgroup 0 logs
@@ -925,7 +931,7 @@ __device__ __forceinline__ void loss_block(
     }
     constexpr int D = 5 * BX + C;
     constexpr int S2 = S * S;
-    constexpr int IPB = LOSS_THREADS / S2;      // images per workgroup (the host's choice too)
+    constexpr int IPB = loss_ipb_for(S2);      // images per workgroup (the host's choice too)
     const long long img0 = (long long)bid * IPB;
     const int nitems = IPB * S2;
     // The workgroup's gradients are one contiguous block of the tensor.  The lanes

@@ -38,7 +38,7 @@ int check_shape(int64_t batch, int S, int Bx, int C, int img_size) {
 
 inline int loss_imgs_per_block(int S) {
     const int S2 = S * S;
-    return S2 <= yh::LOSS_THREADS ? yh::LOSS_THREADS / S2 : 1;
+    return S2 <= yh::LOSS_THREADS ? yh::loss_ipb_for(S2) : 1;
 }
 
 inline int64_t loss_blocks(int64_t batch, int S) {
