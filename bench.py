@@ -538,7 +538,7 @@ def measure_kernels(args, torch, dev, K, resident, log, result, batch, rank):
         del sets
     torch.cuda.synchronize()
 
-    traffic, traffic_note = None, "no profiles/traffic.json"
+    traffic, nms_traffic, traffic_note = None, None, "no profiles/traffic.json"
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
@@ -549,6 +549,7 @@ def measure_kernels(args, torch, dev, K, resident, log, result, batch, rank):
                 traffic_note = "profiles/traffic.json was measured on other kernel sources: not reported"
             else:
                 traffic = tj.get("loss_kernel_hbm_bytes_per_launch")
+                nms_traffic = tj.get("nms_kernel_hbm_bytes_per_launch")
                 traffic_note = f"PMC FETCH_SIZE/WRITE_SIZE passes of profile {tj.get('profile')} (rotated buffers)"
         except Exception as exc:
             traffic_note = f"profiles/traffic.json unreadable: {exc!r}"
@@ -580,6 +581,11 @@ def measure_kernels(args, torch, dev, K, resident, log, result, batch, rank):
         cc = copy_ceiling(torch, dev, st)
         roof["copy_ceiling"] = cc
         roof["frac_of_copy_ceiling"] = achieved / cc["gbs"]
+        if rot and rot.get("step_us") and traffic and nms_traffic:
+            # the whole step (both kernels, two streams) over rotating buffers: the HBM bytes the
+            # two kernels move by the PMC counters / the step's duration, against the copy ceiling
+            rot["step_hbm_gbs"] = (traffic + nms_traffic) / (rot["step_us"] * 1e-6) / 1e9
+            rot["step_frac_of_copy_ceiling"] = rot["step_hbm_gbs"] / cc["gbs"]
     result["roofline"] = roof
     if args.measure == "all" and not args.no_stress:
         result["configs"] = {"nms_stress": stress_record(args, torch, dev, st)}
