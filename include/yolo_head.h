@@ -223,16 +223,18 @@ int yh_scale_grad(float* grad, const float* scale, int64_t n, void* stream);
 
 /*
  * Pairwise box geometry.  Replaces eval.get_area (eval.py:22-32),
- * get_intersection_area (:35-50), get_iou (:53-65) and get_giou (:68-83); the
+ * get_intersection_area (:35-50), get_iou (:53-65), get_smallest_enclosing_area (:68-73)
+ * and get_giou (:76-83); the
  * fp32 results are bit-identical to the reference's PyTorch expressions (IEEE
  * division, no fused multiply-add).
  *   ltrb1 (N, 4), ltrb2 (M, 4), both 16-byte aligned; out (N, M) row-major.
- *   kind: YH_BOX_IOU, YH_BOX_GIOU or YH_BOX_INTERSECTION.
+ *   kind: YH_BOX_IOU, YH_BOX_GIOU, YH_BOX_INTERSECTION or YH_BOX_ENCLOSING.
  * yh_box_area: out[i] = max(r-l, 0) * max(b-t, 0) for n boxes.
  */
 #define YH_BOX_IOU 0
 #define YH_BOX_GIOU 1
 #define YH_BOX_INTERSECTION 2
+#define YH_BOX_ENCLOSING 3
 int yh_pairwise_boxes(const float* ltrb1, const float* ltrb2, float* out, int64_t N, int64_t M,
                       int kind, void* stream);
 int yh_box_area(const float* ltrb, float* out, int64_t n, void* stream);

@@ -71,6 +71,15 @@ def get_iou(ltrb1: torch.Tensor, ltrb2: torch.Tensor) -> torch.Tensor:
     return torch.where(union == 0, 0.0, inter / union)
 
 
+def get_smallest_enclosing_area(bbox1: torch.Tensor, bbox2: torch.Tensor) -> torch.Tensor:
+    """eval.py:68-73."""
+    l = torch.minimum(bbox1[:, 0][:, None], bbox2[:, 0][None, :])
+    t = torch.minimum(bbox1[:, 1][:, None], bbox2[:, 1][None, :])
+    r = torch.maximum(bbox1[:, 2][:, None], bbox2[:, 2][None, :])
+    b = torch.maximum(bbox1[:, 3][:, None], bbox2[:, 3][None, :])
+    return torch.clip(r - l, min=0) * torch.clip(b - t, min=0)
+
+
 def get_giou(bbox1: torch.Tensor, bbox2: torch.Tensor) -> torch.Tensor:
     """eval.py:68-83: pairwise GIoU = IoU - (C - union)/C with C the area of the
     smallest enclosing box; -1 where C == 0."""

@@ -19,6 +19,17 @@ def test_oracle_giou_matches_reference(golden):
     assert giou[2, 2] == 1             # identical boxes
 
 
+def test_oracle_enclosing_area_is_the_one_inside_the_reference_giou(golden):
+    """eval.py:68-73 has no fixture of its own; the reference's GIoU (fixture g1) is built from
+    it, and rebuilding that GIoU from the oracle's enclosing area gives the fixture's bits."""
+    g = golden("g1_iou.npz")
+    b1, b2 = t(g["ltrb1"]), t(g["ltrb2"])
+    c = ref_cpu.get_smallest_enclosing_area(b1, b2)
+    union = ref_cpu.get_area(b1)[:, None] + ref_cpu.get_area(b2)[None, :] - ref_cpu.get_intersection_area(b1, b2)
+    giou = torch.where(c == 0, -1, ref_cpu.get_iou(b1, b2) - ((c - union) / c))
+    assert torch.equal(giou, t(g["giou"]))
+
+
 @pytest.mark.gpu
 def test_gpu_geometry_bit_exact_against_reference_fixture(dev, golden):
     from yolo_amd import box_ops
@@ -29,6 +40,8 @@ def test_gpu_geometry_bit_exact_against_reference_fixture(dev, golden):
                     (box_ops.get_intersection_area, "inter")):
         got = fn(b1, b2).cpu().numpy()
         np.testing.assert_array_equal(got.view(np.uint32), g[key].view(np.uint32))
+    enc = box_ops.get_smallest_enclosing_area(b1, b2).cpu()
+    assert torch.equal(enc, ref_cpu.get_smallest_enclosing_area(b1.cpu(), b2.cpu()))
     np.testing.assert_array_equal(box_ops.get_area(b1).cpu().numpy(), g["area1"])
     np.testing.assert_array_equal(box_ops.get_area(b2).cpu().numpy(), g["area2"])
 
@@ -42,7 +55,8 @@ def test_gpu_geometry_larger_and_ragged(dev):
         a = torch.rand(n, 4, generator=gen) * 64
         b = torch.rand(m, 4, generator=gen) * 64                    # many inverted boxes
         for fn, ref in ((box_ops.get_iou, ref_cpu.get_iou), (box_ops.get_giou, ref_cpu.get_giou),
-                        (box_ops.get_intersection_area, ref_cpu.get_intersection_area)):
+                        (box_ops.get_intersection_area, ref_cpu.get_intersection_area),
+                        (box_ops.get_smallest_enclosing_area, ref_cpu.get_smallest_enclosing_area)):
             got = fn(a.to(dev), b.to(dev)).cpu()
             want = ref(a, b)
             assert got.shape == want.shape

@@ -43,6 +43,7 @@ YH_STATIC_SCRATCH_BYTES = 262144
 YH_BOX_IOU = 0
 YH_BOX_GIOU = 1
 YH_BOX_INTERSECTION = 2
+YH_BOX_ENCLOSING = 3
 
 # name -> (restype, argtypes); mirrors include/yolo_head.h declaration by declaration
 SIGNATURES = {

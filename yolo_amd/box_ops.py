@@ -51,6 +51,11 @@ def get_iou(ltrb1, ltrb2):
     return _pairwise(ltrb1, ltrb2, _lib.YH_BOX_IOU)
 
 
+def get_smallest_enclosing_area(bbox1, bbox2):
+    """eval.py:68-73: (N, 4), (M, 4) -> (N, M), the area of the smallest box around each pair."""
+    return _pairwise(bbox1, bbox2, _lib.YH_BOX_ENCLOSING)
+
+
 def get_giou(bbox1, bbox2):
     """eval.py:76-83: (N, 4), (M, 4) -> (N, M); -1 where the enclosing box is empty."""
     return _pairwise(bbox1, bbox2, _lib.YH_BOX_GIOU)

@@ -6,7 +6,7 @@
 
 namespace yh {
 
-constexpr int BOX_IOU = 0, BOX_GIOU = 1, BOX_INTERSECTION = 2;
+constexpr int BOX_IOU = 0, BOX_GIOU = 1, BOX_INTERSECTION = 2, BOX_ENCLOSING = 3;
 
 // grid: x covers the columns j (grid-stride), y covers the rows i (grid-stride).
 // A lane keeps its column's box and area in registers and walks down the rows
@@ -14,6 +14,12 @@ constexpr int BOX_IOU = 0, BOX_GIOU = 1, BOX_INTERSECTION = 2;
 // pass, so that four independent quotients are in flight.
 template <int KIND>
 __device__ __forceinline__ float pair_value(const Box& p, float ap, const Box& q, float aq) {
+    if constexpr (KIND == BOX_ENCLOSING) {
+        // get_smallest_enclosing_area (eval.py:68-73)
+        const float ew = fmaxf(fmaxf(p.r, q.r) - fminf(p.l, q.l), 0.0f);
+        const float eh = fmaxf(fmaxf(p.b, q.b) - fminf(p.t, q.t), 0.0f);
+        return ew * eh;
+    }
     // get_intersection_area (eval.py:46-50)
     const float iw = fmaxf(fminf(p.r, q.r) - fmaxf(p.l, q.l), 0.0f);
     const float ih = fmaxf(fminf(p.b, q.b) - fmaxf(p.t, q.t), 0.0f);

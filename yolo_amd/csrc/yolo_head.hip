@@ -536,7 +536,9 @@ int yh_scale_grad(float* grad, const float* scale, int64_t n, void* stream) {
 int yh_pairwise_boxes(const float* ltrb1, const float* ltrb2, float* out, int64_t N, int64_t M,
                       int kind, void* stream) {
     if (N < 0 || M < 0 || N > ((int64_t)1 << 31) || M > ((int64_t)1 << 31)) return YH_ERR_SHAPE;
-    if (kind != YH_BOX_IOU && kind != YH_BOX_GIOU && kind != YH_BOX_INTERSECTION) return YH_ERR_ARG;
+    if (kind != YH_BOX_IOU && kind != YH_BOX_GIOU && kind != YH_BOX_INTERSECTION &&
+        kind != YH_BOX_ENCLOSING)
+        return YH_ERR_ARG;
     if (N == 0 || M == 0) return YH_OK;
     if (!ltrb1 || !ltrb2 || !out) return YH_ERR_NULL;
     if (!aligned(ltrb1, 16) || !aligned(ltrb2, 16) || !aligned(out, 4)) return YH_ERR_ALIGN;
@@ -552,6 +554,9 @@ int yh_pairwise_boxes(const float* ltrb1, const float* ltrb2, float* out, int64_
     else if (kind == YH_BOX_GIOU)
         hipLaunchKernelGGL(yh::pairwise_boxes_kernel<yh::BOX_GIOU>, grid, dim3(256), 0, st, ltrb1,
                            ltrb2, out, (long long)N, (long long)M);
+    else if (kind == YH_BOX_ENCLOSING)
+        hipLaunchKernelGGL(yh::pairwise_boxes_kernel<yh::BOX_ENCLOSING>, grid, dim3(256), 0, st,
+                           ltrb1, ltrb2, out, (long long)N, (long long)M);
     else
         hipLaunchKernelGGL(yh::pairwise_boxes_kernel<yh::BOX_INTERSECTION>, grid, dim3(256), 0, st,
                            ltrb1, ltrb2, out, (long long)N, (long long)M);
