@@ -92,3 +92,32 @@ def test_validation_under_inference_mode(dev):
         dets, count = head.postprocess(p2, 0.5, 0.5)
     assert loss.item() == want and not loss.requires_grad
     assert int(count.sum()) > 0 and dets.shape == (8, 98, 6)
+
+
+def test_evaluation_pass_matches_the_oracle(dev):
+    """examples/eval_step.py: postprocess -> pooled rows -> get_map, all on the device, against
+    the CPU oracle's post-processing and the reference's metric on the same rows."""
+    import importlib.util
+    import os
+
+    import numpy as np
+
+    from oracle import ref_cpu
+    from yolo_amd import synth
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "eval_step.py")
+    spec = importlib.util.spec_from_file_location("eval_step", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    head = YOLOv1Head()
+    out = synth.make_pred(24, seed=4)
+    ltrb, label, cnt = synth.make_gt_boxes(24, seed=5)
+    m, pred, gt = mod.evaluate(head, out.to(dev), ltrb.to(dev), label.to(dev), cnt.to(dev), 0.3, 0.5, 2.0)
+    wd, wc, _ = ref_cpu.postprocess(out, 0.3, 0.5, mode=0)
+    want_pred = np.concatenate([np.asarray(wd)[b, : int(wc[b])] for b in range(24)], axis=0)
+    # the candidates' boxes and scores are decoded on the GPU (exp within a few ulp of the
+    # CPU's), so the pooled rows are compared to tolerance and the metric on the GPU's own rows
+    assert pred.shape == want_pred.shape
+    np.testing.assert_allclose(pred.cpu().numpy(), want_pred, rtol=1e-5, atol=2e-4)
+    assert m.item() == ref_cpu.get_map(pred.cpu(), gt.cpu(), 20, 2.0)
+    assert m.item() > 0
