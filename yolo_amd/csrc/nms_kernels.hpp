@@ -27,6 +27,8 @@
 namespace yh {
 
 constexpr int NMS_BLOCK = 256;
+// threads of a workgroup: 256, or the image's whole group when that is larger
+constexpr int nms_block_threads(int nt) { return nt > NMS_BLOCK ? nt : NMS_BLOCK; }
 
 struct NmsArgs {
     // source 0: the head tensor; source 2: the head tensor before the last layer's
@@ -165,7 +167,7 @@ __device__ __forceinline__ void group_sync() {
 template <int NT, int ITEMS, int SRC, int S_CT, int BX_CT, int C_CT, bool CM = false>
 __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsigned char* smem) {
     static_assert(!CM || (S_CT == 0 && SRC == 0), "cell-major tensors take the run-time-shape path");
-    constexpr int IPB = NMS_BLOCK / NT;  // images per workgroup
+    constexpr int IPB = nms_block_threads(NT) / NT;  // images per workgroup
     constexpr bool kHead = SRC == 0 || SRC == 2;   // candidates decoded from the head tensor
     constexpr bool kBias = SRC == 2;               // ... to which a bias is added on the way in
     // class-bucketed ranking: a workgroup per image, class count known and bounded
@@ -282,6 +284,76 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             }
         } else {
             // slot = cell*nb + k; the class is computed once per cell
+            constexpr bool kSplit = kStatic && NT >= 2 * (S_CT * S_CT) && C_CT >= 32 && C_CT % 16 == 0;
+            float blog[ITEMS][5];     // kSplit: the candidates' own logits, requested early
+            if constexpr (kSplit) {
+                // More threads than cells: a cell's classes are shared out in slices of 16, a
+                // (slice, cell) pair per work item, every item's 16 logits requested before
+                // the first is looked at -- one round trip, as when a lane takes a whole
+                // cell, at a fraction of the registers.  The slices meet in LDS; the lowest
+                // slice wins a tie (first index).
+                constexpr int NSL = C_CT / 16;                       // slices per cell
+                constexpr int NITEM = NSL * S_CT * S_CT;             // (slice, cell) pairs
+                constexpr int PER = (NITEM + NT - 1) / NT;           // per thread
+                float* smax = reinterpret_cast<float*>(keys);        // the keys are formed later
+                int* sarg = reinterpret_cast<int*>(smax + NITEM);
+                static_assert(NITEM * 8 <= NT * ITEMS * 8, "the partial results fit the key array");
+                // the thread's own candidates' box and confidence logits travel with the class logits
+#pragma unroll
+                for (int e = 0; e < ITEMS; ++e) {
+                    const int n = e * NT + t;
+                    const int cell = n < nslot ? n / BX_CT : 0;
+                    const int k = n < nslot ? n - cell * BX_CT : 0;
+                    const float* q = pimg + cell + (size_t)(5 * k) * S2;
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) blog[e][u] = q[u * S2];
+                    if constexpr (kBias) {
+                        const float* bq = a.bias + cell + (size_t)(5 * k) * S2;
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) blog[e][u] += bq[u * S2];
+                    }
+                }
+                float v[PER][16];
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int w = t + NT * i;
+                    const int sl = w < NITEM ? w / (S_CT * S_CT) : 0;
+                    const int cell = w < NITEM ? w - sl * (S_CT * S_CT) : 0;
+                    const float* p = pimg + cell + (size_t)(5 * BX_CT + 16 * sl) * S2;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[i][u] = p[u * S2];
+                    if constexpr (kBias) {
+                        const float* bq = a.bias + cell + (size_t)(5 * BX_CT + 16 * sl) * S2;
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) v[i][u] += bq[u * S2];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int w = t + NT * i;
+                    if (w < NITEM) {
+                        const int sl = w / (S_CT * S_CT);
+                        float m = v[i][0];
+                        int best = 0;
+#pragma unroll
+                        for (int u = 1; u < 16; ++u)
+                            if (v[i][u] > m) { m = v[i][u]; best = u; }
+                        smax[w] = m;
+                        sarg[w] = 16 * sl + best;
+                    }
+                }
+                group_sync<NT>();
+                if (t < S2) {
+                    float m = smax[t];
+                    int best = sarg[t];
+#pragma unroll
+                    for (int sl = 1; sl < NSL; ++sl) {
+                        const float x = smax[sl * S2 + t];
+                        if (x > m) { m = x; best = sarg[sl * S2 + t]; }
+                    }
+                    ccls[t] = best;
+                }
+            } else
 #pragma unroll
             for (int e = 0; e < ITEMS; ++e) {   // S*S <= nslot <= NT*ITEMS
                 const int cell = e * NT + t;
@@ -313,7 +385,12 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                     const int k = n - cell * nb;
                     const MemLogitsT<kBias> q{pimg + cell * cells + (5 * k) * chs,
                                               kBias ? a.bias + cell + (5 * k) * S2 : nullptr, chs};
-                    const float lx = q(0), ly = q(1), lw = q(2), lh = q(3), lc = q(4);
+                    float lx, ly, lw, lh, lc;
+                    if constexpr (kSplit) {
+                        lx = blog[e][0]; ly = blog[e][1]; lw = blog[e][2]; lh = blog[e][3]; lc = blog[e][4];
+                    } else {
+                        lx = q(0); ly = q(1); lw = q(2); lh = q(3); lc = q(4);
+                    }
                     cbox[e] = box_from_logits(lx, ly, lw, lh, cell, S, a.cellf, a.imgf);
                     cscore[e] = sigmoidf_(lc);
                     ccl[e] = ccls[cell];
@@ -477,7 +554,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         // comparisons instead of N * N).
         int* hist = reinterpret_cast<int*>(region + a.off_hist);    // per class: count, then fill cursor
         int* segst = reinterpret_cast<int*>(region + a.off_segst);  // per class: first sorted position
-        int* wtot = misc + 4;                                       // per wavefront: scan carry
+        int* wtot = misc + 8;                                       // per wavefront: scan carry
         const int nc = a.nc;
         for (int c = t; c < nc; c += NT) hist[c] = 0;
         group_sync<NT>();
@@ -869,9 +946,17 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
 }
 
 template <int NT, int ITEMS, int SRC, int S_CT, int BX_CT, int C_CT, bool CM = false>
-__global__ __launch_bounds__(NMS_BLOCK) void nms_kernel(const NmsArgs a) {
+__global__ __launch_bounds__(nms_block_threads(NT)) void nms_kernel(const NmsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     nms_block<NT, ITEMS, SRC, S_CT, BX_CT, C_CT, CM>(a, (int)blockIdx.x, smem);
+}
+
+// 512 threads per image at eight wavefronts per SIMD (at most 64 registers a lane):
+// four images share a CU as with nms_kernel<256, 4>, each with twice the wavefronts
+template <int ITEMS, int SRC, int S_CT, int BX_CT, int C_CT>
+__global__ __launch_bounds__(512, 8) void nms_kernel_wide(const NmsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    nms_block<512, ITEMS, SRC, S_CT, BX_CT, C_CT>(a, (int)blockIdx.x, smem);
 }
 
 // ---- candidates to global memory (the values nms_kernel<.,.,0> forms in registers) ---

@@ -74,7 +74,7 @@ void nms_layout(yh::NmsArgs& a, int slot_pad, int imgs_per_block = 1) {
     a.off_alive = off;
     off += round16((slot_pad / 64) * 8);
     a.off_misc = off;
-    off += 32;
+    off += 128;
     a.off_ccls = off;
     off += round16(a.S * a.S * 4);
     a.off_hist = off;     // class histogram / bucket cursors and bucket starts (fused path)
@@ -110,13 +110,14 @@ template <int SRC, int S_CT, int BX_CT, int C_CT, bool CM = false>
 int launch_nms_shape(yh::NmsArgs a, hipStream_t st) {
 #define YH_NMS_CASE(NT, ITEMS)                                                              \
     {                                                                                       \
-        nms_layout(a, NT * ITEMS, yh::NMS_BLOCK / NT);                                      \
-        const int ipb = yh::NMS_BLOCK / NT;                                                 \
+        constexpr int threads = yh::nms_block_threads(NT);                                  \
+        nms_layout(a, NT * ITEMS, threads / NT);                                            \
+        const int ipb = threads / NT;                                                       \
         const unsigned grid = (unsigned)((a.batch + ipb - 1) / ipb);                        \
         const size_t lds = (size_t)a.region_bytes * ipb;                                    \
         if (lds > kLdsBudget) return YH_ERR_UNSUPPORTED;                                    \
         hipLaunchKernelGGL((yh::nms_kernel<NT, ITEMS, SRC, S_CT, BX_CT, C_CT, CM>), dim3(grid), \
-                           dim3(yh::NMS_BLOCK), lds, st, a);                                \
+                           dim3(threads), lds, st, a);                                      \
         return launch_status();                                                             \
     }
     // a compile-time shape has two possible slot counts (S*S and S*S*Bx): only the
@@ -128,7 +129,22 @@ int launch_nms_shape(yh::NmsArgs a, hipStream_t st) {
     if constexpr (YH_NMS_FITS(64, 128)) if (a.nslot <= 128) YH_NMS_CASE(64, 2)
     if constexpr (YH_NMS_FITS(128, 256)) if (a.nslot <= 256) YH_NMS_CASE(256, 1)
     if constexpr (YH_NMS_FITS(256, 512)) if (a.nslot <= 512) YH_NMS_CASE(256, 2)
-    if constexpr (YH_NMS_FITS(512, 1024)) if (a.nslot <= 1024) YH_NMS_CASE(256, 4)
+    if constexpr (YH_NMS_FITS(512, 1024)) if (a.nslot <= 1024) {
+        // A compile-time shape whose class logits can be shared out over more threads than
+        // cells (the stress shape S=14, Bx=5, C=80): 512 threads per image at 64 registers,
+        // so that four images still share a CU, each with twice the wavefronts (43.9 against
+        // 46.8 us at batch 1024, 21.9 against 29.9 at 256, 162.7 against 182.6 at 4096)
+        if constexpr (S_CT > 0 && 2 * S_CT * S_CT <= 512 && C_CT >= 32 && C_CT % 16 == 0) {
+            if (a.mode == YH_MODE_DENSE) {
+                nms_layout(a, 1024, 1);
+                if ((size_t)a.region_bytes > kLdsBudget) return YH_ERR_UNSUPPORTED;
+                hipLaunchKernelGGL((yh::nms_kernel_wide<2, SRC, S_CT, BX_CT, C_CT>),
+                                   dim3((unsigned)a.batch), dim3(512), (size_t)a.region_bytes, st, a);
+                return launch_status();
+            }
+        }
+        YH_NMS_CASE(256, 4)
+    }
     if constexpr (YH_NMS_FITS(1024, 2048)) if (a.nslot <= 2048) YH_NMS_CASE(256, 8)
     return YH_ERR_UNSUPPORTED;
 #undef YH_NMS_FITS
