@@ -72,6 +72,44 @@ def test_decode_nms_on_a_channels_last_tensor(dev, S, Bx, C, batch):
             np.testing.assert_array_equal(g_.cpu().numpy().view(np.uint32), w.cpu().numpy().view(np.uint32))
 
 
+@pytest.mark.parametrize("S,Bx,C", [(14, 5, 80), (13, 5, 20), (9, 3, 130), (7, 2, 1000)])
+def test_class_ties_and_nans_when_lanes_share_a_cell(dev, S, Bx, C):
+    """A block too large to stage: 16 lanes take a cell's class logits together.  Equal
+    maxima (the first index wins), -inf rows and NaNs (only one at class 0 counts) must
+    come out as when one lane walks the cell (the channel-major kernel)."""
+    img = 32 * S
+    head = YOLOv1Head(img_size=img, n_cells=S, n_bboxes=Bx, n_classes=C)
+    g = torch.Generator().manual_seed(S * 1000 + C)
+    batch = 6
+    pred = synth.make_inputs(batch, S, Bx, C, img, seed=3)[0]
+    cls = pred[:, 5 * Bx:]                                  # (batch, C, S, S), a view
+    cls.copy_(torch.randint(-3, 4, cls.shape, generator=g).float())   # many equal maxima
+    cls[1].fill_(float("-inf"))
+    cls[2, 0] = float("nan")                                # NaN at class 0: class 0
+    cls[3, C // 2] = float("nan")                           # elsewhere: passed over
+    cls[3, min(17, C - 1), ::2] = float("inf")
+    cls[4, :, 1::2, :] = 2.5                                # a whole cell equal
+    cls[5, C - 1] = 7.0                                     # the last class, in the last lane's share
+    pred = pred.to(dev)
+    for mode, ct in ((MODE_REFERENCE, 0.3), (MODE_DENSE, 0.001)):
+        want = head.postprocess(pred, ct, 0.5, mode, return_idx=True)
+        got = head.postprocess(channels_last(pred), ct, 0.5, mode, return_idx=True)
+        for g_, w in zip(got, want):
+            np.testing.assert_array_equal(g_.cpu().numpy().view(np.uint32), w.cpu().numpy().view(np.uint32))
+    # and the classes themselves against the oracle's argmax on one image
+    dets, cnt, idx = head.postprocess(channels_last(pred), 0.0, 2.0, MODE_DENSE, return_idx=True)
+    want_cls = ref_cpu_classes(pred[5].cpu(), Bx)
+    got_cls = torch.empty(S * S, dtype=torch.long)
+    k = int(cnt[5].item())
+    got_cls[(idx[5, :k].cpu().long() // Bx)] = dets[5, :k, 5].cpu().long()
+    assert torch.equal(got_cls, want_cls)
+
+
+def ref_cpu_classes(pred_img, Bx):
+    """argmax over the class channels per cell, row-major cells (model.py:389)."""
+    return torch.argmax(pred_img[5 * Bx:], dim=0).reshape(-1)
+
+
 def test_argument_errors_and_limits(dev):
     lib = _lib.load()
     f = 0x1000

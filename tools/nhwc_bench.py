@@ -22,7 +22,9 @@ for S, BX, C, B in ((7, 2, 20, 4096), (7, 2, 24, 4096), (14, 2, 20, 1024), (14, 
     grad = torch.empty_like(pred); terms = torch.empty(5, device=dev)
     dets = torch.empty(B, S * S * BX, 6, device=dev); cnt = torch.empty(B, dtype=torch.int32, device=dev)
     def loss(fn, p): _lib.check(fn(p.data_ptr(), gx.data_ptr(), gc.data_ptr(), om8.data_ptr(), grad.data_ptr(), terms.data_ptr(), ws.data_ptr(), ws.numel(), B, S, BX, C, 32 * S, 5.0, 0.5, 1.0 / B, st))
-    def nms(fn, p): _lib.check(fn(p.data_ptr(), dets.data_ptr(), cnt.data_ptr(), None, 0, 0.5, 0.5, B, S, BX, C, 32 * S, st))
+    def nms(fn, p, mode=0, conf=0.5): _lib.check(fn(p.data_ptr(), dets.data_ptr(), cnt.data_ptr(), None, mode, conf, 0.5, B, S, BX, C, 32 * S, st))
     print(f"S={S:2d} B={BX} C={C:2d} batch {B}: loss {b2b(lambda: loss(lib.yh_loss_fwd_bwd, pred)):6.1f} us channel-major, "
           f"{b2b(lambda: loss(lib.yh_loss_fwd_bwd_nhwc, pcl)):6.1f} us cell-major | decode+NMS "
           f"{b2b(lambda: nms(lib.yh_decode_nms, pred)):6.1f} us channel-major, {b2b(lambda: nms(lib.yh_decode_nms_nhwc, pcl)):6.1f} us cell-major")
+    print(f"      dense candidates, conf 0.001: decode+NMS {b2b(lambda: nms(lib.yh_decode_nms, pred, 1, 0.001)):6.1f} us channel-major, "
+          f"{b2b(lambda: nms(lib.yh_decode_nms_nhwc, pcl, 1, 0.001)):6.1f} us cell-major")

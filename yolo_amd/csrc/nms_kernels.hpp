@@ -222,6 +222,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         // floats between two channels of a cell and between two cells of a channel
         const int chs = CM ? 1 : S2;
         const int cells = CM ? (int)D : 1;
+        bool cls_ready = false;    // the cells' classes are in ccls already
         if constexpr (CM) {
             // A lane's cell is D floats away from its neighbour's: read from memory cell by
             // cell, a wavefront load would touch a line per lane.  The image's block comes in
@@ -233,6 +234,36 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                 for (int i = t; i < nfl; i += NT) stage[i] = pimg[i];
                 group_sync<NT>();
                 pimg = stage;
+            } else {
+                // No room: 16 lanes share a cell's class logits, each wavefront load covering
+                // 64 consecutive bytes of four cells, and settle the argmax among themselves
+                // (first index on ties; a NaN counts only at index 0, as in cell_class_mem).
+                const int l16 = t & 15;
+                const int rounds = (S2 + (NT >> 4) - 1) / (NT >> 4);
+                for (int r = 0; r < rounds; ++r) {
+                    const int cell_raw = r * (NT >> 4) + (t >> 4);
+                    const int cell = min(cell_raw, S2 - 1);
+                    const float* p = pimg + (size_t)cell * cells + 5 * nb;
+                    float m = l16 == 0 ? p[0] : -INFINITY;
+                    int best = l16 == 0 ? 0 : 0x7fffffff;
+                    for (int j0 = l16 == 0 ? 16 : l16; j0 < nc; j0 += 64) {
+                        float v4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v4[u] = j0 + 16 * u < nc ? p[j0 + 16 * u] : 0.0f;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (j0 + 16 * u < nc && v4[u] > m) { m = v4[u]; best = j0 + 16 * u; }
+                    }
+#pragma unroll
+                    for (int o = 8; o >= 1; o >>= 1) {
+                        const float om = __shfl_xor(m, o, 16);
+                        const int ob = __shfl_xor(best, o, 16);
+                        if (om > m || (om == m && ob < best)) { m = om; best = ob; }
+                    }
+                    if (l16 == 0 && cell_raw < S2) ccls[cell] = best;
+                }
+                group_sync<NT>();
+                cls_ready = true;
             }
         }
         if (a.mode == 0) {
@@ -275,7 +306,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                         const MemLogitsT<kBias> logit{p, kBias ? a.bias + cell : nullptr, chs};
                         k = cell_best_conf(logit, nb, cb);
                         cbox[e] = cell_box(logit, k, cell, S, a.cellf, a.imgf);
-                        ccl[e] = cell_class_mem(logit, 5 * nb, nc);
+                        ccl[e] = cls_ready ? ccls[cell] : cell_class_mem(logit, 5 * nb, nc);
                     }
                     cscore[e] = cb;
                     cidx[e] = cell * nb + k;
@@ -357,7 +388,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
 #pragma unroll
             for (int e = 0; e < ITEMS; ++e) {   // S*S <= nslot <= NT*ITEMS
                 const int cell = e * NT + t;
-                if (cell >= S2) continue;
+                if (cell >= S2 || cls_ready) continue;
                 const float* p = pimg + cell * cells;
                 if constexpr (kStatic) {
                     float v[C_CT];

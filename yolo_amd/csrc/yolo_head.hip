@@ -91,7 +91,10 @@ void nms_layout(yh::NmsArgs& a, int slot_pad, int imgs_per_block = 1) {
     // small enough to leave room for a second workgroup on the CU
     a.off_stage = -1;
     const int block_bytes = (5 * a.nb + a.nc) * a.S * a.S * 4;
-    if (a.cell_major && (long long)block_bytes * imgs_per_block <= 48 * 1024) {
+    // (with a candidate per predictor the tables are large already and a block above 8 KB costs
+    // a workgroup per CU: 16 lanes per cell read it from memory instead, see nms_block)
+    const int stage_budget = a.mode == YH_MODE_DENSE ? 8 * 1024 * imgs_per_block : 48 * 1024;
+    if (a.cell_major && (long long)block_bytes * imgs_per_block <= stage_budget) {
         a.off_stage = off;
         off += round16(block_bytes);
     }
