@@ -83,6 +83,47 @@ def test_nms_bit_exact(dev, batch, n, ncls, ct, it):
     assert_same(got, oracle_nms(ltrb, score, cls, present, ct, it))
 
 
+def test_class_segments_around_the_block_length(dev):
+    """A class segment is worked on in blocks of 64 members, a round per block: segments of
+    1, 63, 64, 65, 127, 128, 129, 192 and 193 members side by side in one image, overlapping
+    heavily, so that survivors of an early block must stop members of the later ones."""
+    lens = [1, 63, 64, 65, 127, 128, 129, 192, 193]
+    n = sum(lens)                                        # 962 candidates
+    g = torch.Generator().manual_seed(11)
+    cls = torch.cat([torch.full((m,), c, dtype=torch.int32) for c, m in enumerate(lens)])
+    batch = 3
+    c = torch.rand(batch, n, 2, generator=g) * 120 + 100      # crowded: many IoUs above 0.3
+    wh = torch.rand(batch, n, 2, generator=g) * 60 + 30
+    ltrb = torch.cat([c - wh / 2, c + wh / 2], dim=-1).contiguous()
+    score = torch.rand(batch, n, generator=g)
+    score[1] = (score[1] * 8).floor() / 8                     # equal scores: order by index
+    perm = torch.randperm(n, generator=g)
+    cls_b = cls[perm].unsqueeze(0).expand(batch, n).contiguous()
+    present = torch.ones(batch, n, dtype=torch.bool)
+    for it in (0.3, 0.5, 0.05):
+        got = YOLOv1Head.nms(ltrb.to(dev), score.to(dev), cls_b.to(dev), present.to(dev), 0.0, it,
+                             return_idx=True)
+        assert_same(got, oracle_nms(ltrb, score, cls_b, present, 0.0, it))
+
+
+@pytest.mark.parametrize("S,Bx,C", [(14, 5, 80), (13, 5, 20), (10, 5, 3), (20, 5, 80)])
+def test_one_class_takes_most_cells(dev, S, Bx, C):
+    """Detections of a real image crowd into few classes: one class wins 70 % of the cells
+    (segments of several hundred members), through the fused kernels."""
+    img = 32 * S
+    head = YOLOv1Head(img_size=img, n_cells=S, n_bboxes=Bx, n_classes=C)
+    pred = synth.make_pred(4, S, Bx, C, seed=S + C)
+    g = torch.Generator().manual_seed(S)
+    crowd = torch.rand(4, S, S, generator=g) < 0.7
+    pred[:, 5 * Bx + C // 2][crowd] += 30.0
+    pred = pred.to(dev)
+    for ct, it in ((0.001, 0.5), (0.2, 0.3)):
+        got = head.postprocess(pred, ct, it, MODE_DENSE, return_idx=True)
+        ltrb, score, cls, present = head.decode_candidates(pred, MODE_DENSE)
+        assert int((cls[0] == C // 2).sum()) > 64
+        assert_same(got, oracle_nms(ltrb, score, cls, present, ct, it))
+
+
 def test_iou_threshold_on_and_next_to_a_pair_iou(dev):
     """The workgroup-per-image kernel decides IoU > threshold without dividing;
     thresholds that ARE the IoU of some pair, and the floats next to it on either

@@ -694,8 +694,12 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         mybox[e] = {0.f, 0.f, 0.f, 0.f};
         mymeta[e] = make_int4(0, 0, 0, 0);
         if (al[e]) {
-            const float4 b = sbox[i];
-            mybox[e] = {b.x, b.y, b.z, b.w};
+            // a workgroup per image: the sorted boxes stay in LDS to the end and are read
+            // again where they are needed, instead of living in registers through phase D
+            if constexpr (NT == 64) {
+                const float4 b = sbox[i];
+                mybox[e] = {b.x, b.y, b.z, b.w};
+            }
             const int2 m = smeta[i];
             mymeta[e] = make_int4(m.x, m.y >> 16, m.y & 0xffff, kWave ? 0 : sseg[i]);
         }
@@ -760,27 +764,37 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             pos_out[e] = total + __popcll(aw[e] & ((1ull << lane) - 1ull));
             total += __popcll(aw[e]);
         }
-    } else if (maxpos < 64) {
-        // A workgroup per image, no class segment longer than 64.  The pairs
-        // (earlier member i, later member p) of all segments are spread evenly over
-        // the threads, whatever the segment lengths; a pair whose IoU exceeds the
-        // threshold sets bit (index of p in the segment) in the word of i.  One lane
-        // per segment then walks its members in order: a member still alive kills
-        // the members in its word.  No barrier per member, and every lane of the
-        // pair loop has work.
+    } else {
+        // A workgroup per image.  A class segment is cut into blocks of 64 members.  The
+        // pairs (earlier member i, later member p) inside a block, of all blocks, are
+        // spread evenly over the threads, whatever the block lengths; a pair whose IoU
+        // exceeds the threshold sets bit (index of p in the block) in the word of i.  One
+        // lane per block then walks its members in order: a member still alive kills the
+        // members in its word.  No barrier per member, and every lane of the pair loop has
+        // work.  A segment of more than 64 members takes a round per block: after the walk
+        // of its k-th block the members of the later blocks test themselves against that
+        // block's survivors (a member killed this way clears its own word, so it kills
+        // nobody when its block is walked).  Most images need one round.
+        const int nrounds = (maxpos >> 6) + 1;
         unsigned long long* kills = keys;     // the keys are not needed any more
         // pairs before position p; the array takes the place of smeta, which every
         // thread has read into registers before the barrier below
         int* poff = reinterpret_cast<int*>(region + a.off_pair);
-        int* slen = poff + NT * ITEMS;        // at a segment's first position: its member count
+        int* slen = poff + NT * ITEMS;        // at a block's first position: its member count
         // pairs per chunk of 64, in the liveness words (not written before the greedy pass):
         // this array is filled before the barrier, so it must not overlap smeta
         int* ctot = reinterpret_cast<int*>(alive);
         int r[ITEMS], excl[ITEMS];
+        // my block of the segment, and its first position (i - r[e])
+        auto blk = [&](int e) { return (e * NT + t - r[e] - mymeta[e].w) >> 6; };
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
             const int i = e * NT + t;
-            r[e] = al[e] ? i - mymeta[e].w : 0;   // members of my segment ahead of me
+            const int pos = al[e] ? i - mymeta[e].w : 0;
+            r[e] = pos & 63;                      // members of my block ahead of me
+            // the pair loop and the block lengths go by block starts (this thread alone has
+            // read sseg[i] so far)
+            if (nrounds > 1 && al[e]) sseg[i] = i - r[e];
             int incl = r[e];
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -791,7 +805,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             if (lane == 63) ctot[e * NW + wv] = incl;
             if (al[e]) kills[i] = 0ull;
         }
-        if (t == 0) misc[2] = 0;   // number of segment heads queued below
+        if (t == 0) misc[2] = 0;   // number of block heads queued below
         group_sync<NT>();
         YH_STAMP(9);
         int npairs = 0;
@@ -808,7 +822,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                 const int i = e * NT + t;
                 poff[i] = carry + excl[e];
                 const int nxt = i + 1 < nvalid ? sseg[i + 1] : -1;
-                if (nxt != mymeta[e].w) slen[mymeta[e].w] = r[e] + 1;   // the segment's last member
+                if (nxt != i - r[e]) slen[i - r[e]] = r[e] + 1;   // the block's last member
             }
         }
         group_sync<NT>();
@@ -827,13 +841,13 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                 if (poff[mid] <= k) lo = mid; else hi = mid - 1;
             }
             // Pairs are numbered by later member, then by earlier member, so inside a
-            // segment of L members the walk is register arithmetic: (ii, j) -> (ii + 1, j)
-            // -> ... -> (0, j + 1); the next segment starts at sp + L, and its length is
-            // fetched one segment ahead.
+            // block of L members the walk is register arithmetic: (ii, j) -> (ii + 1, j)
+            // -> ... -> (0, j + 1); the next block starts at sp + L, and its length is
+            // fetched one block ahead.
             const int p = lo;
-            int sp = sseg[p];                     // first position of the segment
+            int sp = sseg[p];                     // first position of the block
             int L = slen[sp];
-            int j = p - sp;                       // later member, as an index into the segment
+            int j = p - sp;                       // later member, as an index into the block
             int ii = k - poff[p];                 // earlier member, ii < j
             int nL = sp + L < nvalid ? slen[sp + L] : 0;
             float4 bp = sbox[p];
@@ -849,8 +863,8 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                     ii = 0;
                     if (++j == L) {
                         if (k + 1 >= kend) break;
-                        // a later pair exists, so a later segment has two members or more;
-                        // one-member segments are stepped over
+                        // a later pair exists, so a later block has two members or more;
+                        // one-member blocks are stepped over
                         do {
                             sp += L;
                             L = nL;
@@ -867,77 +881,81 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
 #ifdef YH_PHASE_PROBE
         if (a.dbg_stop == 6) return;
 #endif
-        // the segment heads queue up in a list (any order: segments are independent)
-        int* hlist = reinterpret_cast<int*>(sbox);   // every box is in registers by now
+        // the block heads queue up in a list (any order: blocks of one round are
+        // independent), each with its block number; the pair offsets are dead by now
+        int* hlist = poff;
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
             const int i = e * NT + t;
-            if (al[e] && r[e] == 0) hlist[atomicAdd(&misc[2], 1)] = i;
+            if (al[e] && r[e] == 0) hlist[atomicAdd(&misc[2], 1)] = i | (blk(e) << 16);
         }
         group_sync<NT>();
         YH_STAMP(12);
-        // one lane per segment: greedy pass over its members, eight words per round trip
         const int nheads = misc[2];
-        for (int h = t; h < nheads; h += NT) {
-            const int head = hlist[h];
-            const int len = slen[head];
-            unsigned long long dead = 0ull;
-            for (int base = 0; base < len; base += 8) {
-                unsigned long long kw[8];
+        const IouBand xband = make_iou_band(a.iou_thr);
+        for (int round = 0; round < nrounds; ++round) {
+            // one lane per block of this round: greedy pass over its members, eight words
+            // per round trip
+            for (int h = t; h < nheads; h += NT) {
+                const int ent = hlist[h];
+                if ((ent >> 16) != round) continue;
+                const int head = ent & 0xffff;
+                const int len = slen[head];
+                unsigned long long dead = 0ull;
+                for (int base = 0; base < len; base += 8) {
+                    unsigned long long kw[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) kw[u] = base + u < len ? kills[head + base + u] : 0ull;
+                    for (int u = 0; u < 8; ++u) kw[u] = base + u < len ? kills[head + base + u] : 0ull;
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (!((dead >> (base + u)) & 1ull)) dead |= kw[u];
-            }
-            kills[head] = dead;
-        }
-        group_sync<NT>();
-        YH_STAMP(13);
-#pragma unroll
-        for (int e = 0; e < ITEMS; ++e) {
-            if (al[e] && ((kills[mymeta[e].w] >> r[e]) & 1ull)) al[e] = false;
-            const unsigned long long w = __ballot(al[e]);
-            if (lane == 0) alive[e * NW + wv] = w;
-        }
-        group_sync<NT>();
-        YH_STAMP(14);
-#pragma unroll
-        for (int w = 0; w < ITEMS * NW; ++w) total += __popcll(alive[w]);
-#pragma unroll
-        for (int e = 0; e < ITEMS; ++e) {
-            const int myw = e * NW + wv;
-            int pos = __popcll(alive[myw] & ((1ull << lane) - 1ull));
-            for (int w = 0; w < myw; ++w) pos += __popcll(alive[w]);
-            pos_out[e] = pos;
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < ITEMS; ++e) {
-            const unsigned long long w = __ballot(al[e]);
-            if (lane == 0) alive[e * NW + wv] = w;
-        }
-        group_sync<NT>();
-        for (int step = 0; step < maxpos; ++step) {
-#pragma unroll
-            for (int e = 0; e < ITEMS; ++e) {
-                const int i = e * NT + t;
-                if (al[e] && i - mymeta[e].w > step) {
-                    const int pv = mymeta[e].w + step;
-                    if ((alive[pv >> 6] >> (pv & 63)) & 1ull) {
-                        const float4 b = sbox[pv];
-                        const Box pb = {b.x, b.y, b.z, b.w};
-                        if (iou_pair(pb, mybox[e]) > a.iou_thr) al[e] = false;
-                    }
+                    for (int u = 0; u < 8; ++u)
+                        if (!((dead >> (base + u)) & 1ull)) dead |= kw[u];
                 }
+                kills[head] = dead;
             }
-            group_sync<NT>();  // every read of the liveness words precedes their update
+            group_sync<NT>();
+            YH_STAMP(13);
 #pragma unroll
             for (int e = 0; e < ITEMS; ++e) {
+                if (al[e] && blk(e) == round && ((kills[e * NT + t - r[e]] >> r[e]) & 1ull)) al[e] = false;
                 const unsigned long long w = __ballot(al[e]);
                 if (lane == 0) alive[e * NW + wv] = w;
             }
             group_sync<NT>();
+            if (round + 1 < nrounds) {
+                // the survivors of block `round` against the members of the later blocks of
+                // their segment (that block is full: 64 positions from its start)
+#pragma unroll
+                for (int e = 0; e < ITEMS; ++e) {
+                    if (al[e] && blk(e) > round) {
+                        const int base = mymeta[e].w + (round << 6);
+                        const int wi = base >> 6, sh = base & 63;
+                        const float4 mb = sbox[e * NT + t];
+                        const Box mine = {mb.x, mb.y, mb.z, mb.w};
+                        unsigned long long aw = alive[wi] >> sh;
+                        if (sh) aw |= alive[wi + 1] << (64 - sh);   // wi + 1 holds my own block or an earlier one
+                        while (aw) {
+                            const int q = __ffsll((long long)aw) - 1;
+                            aw &= aw - 1ull;
+                            const float4 b = sbox[base + q];
+                            if (iou_above_band({b.x, b.y, b.z, b.w}, mine, xband)) {
+                                al[e] = false;
+                                kills[e * NT + t] = 0ull;   // kills nobody when its block is walked
+                                break;
+                            }
+                        }
+                    }
+                }
+                group_sync<NT>();
+            }
+        }
+        YH_STAMP(14);
+        // the survivors' boxes come back from LDS along with the liveness words
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            if (al[e]) {
+                const float4 b = sbox[e * NT + t];
+                mybox[e] = {b.x, b.y, b.z, b.w};
+            }
         }
 #pragma unroll
         for (int w = 0; w < ITEMS * NW; ++w) total += __popcll(alive[w]);
