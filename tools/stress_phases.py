@@ -10,6 +10,10 @@ B = int(os.environ.get("KB_BATCH", "1024"))
 S, BX, C, IMG = 14, 5, 80, 448
 head = YOLOv1Head(IMG, S, BX, C)
 pred = synth.make_inputs(B, S, BX, C, IMG)[0].to(dev)
+CROWD = float(os.environ.get("KB_CROWD", "0"))      # one class wins this share of the cells
+if CROWD > 0:
+    mask = torch.rand(B, S, S, device=dev, generator=torch.Generator(dev).manual_seed(1)) < CROWD
+    pred[:, 5 * BX + 40][mask] += 30.0
 stamps = torch.zeros(B, 16, dtype=torch.int64, device=dev)
 for _ in range(5): head.postprocess(pred, 0.001, 0.5, MODE_DENSE)
 os.environ["YH_NMS_STAMPS"] = str(stamps.data_ptr())
