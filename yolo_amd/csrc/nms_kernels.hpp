@@ -628,18 +628,36 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             if (cvalid[e]) keys[segst[ccl[e]] + atomicAdd(&hist[ccl[e]], 1)] = key[e];
         group_sync<NT>();
         YH_STAMP(6);
-        // rank inside the bucket; the bucket order itself does not matter
+        // Rank inside the bucket; the bucket order itself does not matter.  A thread ranks
+        // the keys at its bucket POSITIONS, not its own candidates: neighbouring lanes are
+        // then in the same bucket, read the same key in every step (one LDS access for all
+        // of them) and run loops of the same length -- a crowded class keeps its own
+        // wavefronts busy, not every wavefront of the image.  The rank goes back to the
+        // candidate's owner through LDS (the slot index is in the key).
+        int* rankof = sseg;                       // not written before phase C
+        const int nbucketed = segst[nc - 1] + hist[nc - 1];
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            const int p = e * NT + t;
+            if (p < nbucketed) {
+                const unsigned long long kp = keys[p];
+                const int c = (int)(kp >> 48);
+                const int s0 = segst[c];
+                const int n = hist[c];
+                int cnt = 0;
+                for (int j = 0; j < n; ++j) cnt += keys[s0 + j] < kp ? 1 : 0;
+                rankof[(int)(kp & 0xffffull)] = s0 + cnt;
+            }
+        }
+        group_sync<NT>();
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
             if (cvalid[e]) {
-                const int s0 = segst[ccl[e]];
-                const int n = hist[ccl[e]];
-                int cnt = 0;
-                for (int j = 0; j < n; ++j) cnt += keys[s0 + j] < key[e] ? 1 : 0;
-                rank[e] = s0 + cnt;
-                seg[e] = s0;
+                rank[e] = rankof[e * NT + t];
+                seg[e] = segst[ccl[e]];
             }
         }
+        group_sync<NT>();     // phase C writes the segment starts over the ranks
     } else {
 #pragma unroll 8
         for (int j = 0; j < nslot; ++j) {
@@ -920,32 +938,47 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                 const unsigned long long w = __ballot(al[e]);
                 if (lane == 0) alive[e * NW + wv] = w;
             }
+            if (t == 0) misc[3] = 0;   // members queued for the test against this block's survivors
             group_sync<NT>();
             if (round + 1 < nrounds) {
-                // the survivors of block `round` against the members of the later blocks of
-                // their segment (that block is full: 64 positions from its start)
+                // The survivors of block `round` against the members of the later blocks of
+                // their segment (that block is full: 64 positions from its start).  The later
+                // members queue up; a wavefront takes one of them at a time, its lanes holding
+                // the 64 pivots (kept in registers while the queue stays in one segment), so a
+                // member costs one IoU test per wavefront instead of a loop over the pivots.
+                int* xlist = sseg;           // the segment starts are dead since the pair loop
 #pragma unroll
                 for (int e = 0; e < ITEMS; ++e) {
-                    if (al[e] && blk(e) > round) {
-                        const int base = mymeta[e].w + (round << 6);
-                        const int wi = base >> 6, sh = base & 63;
-                        const float4 mb = sbox[e * NT + t];
-                        const Box mine = {mb.x, mb.y, mb.z, mb.w};
-                        unsigned long long aw = alive[wi] >> sh;
-                        if (sh) aw |= alive[wi + 1] << (64 - sh);   // wi + 1 holds my own block or an earlier one
-                        while (aw) {
-                            const int q = __ffsll((long long)aw) - 1;
-                            aw &= aw - 1ull;
-                            const float4 b = sbox[base + q];
-                            if (iou_above_band({b.x, b.y, b.z, b.w}, mine, xband)) {
-                                al[e] = false;
-                                kills[e * NT + t] = 0ull;   // kills nobody when its block is walked
-                                break;
-                            }
-                        }
+                    if (al[e] && blk(e) > round)
+                        xlist[atomicAdd(&misc[3], 1)] = (e * NT + t) | (mymeta[e].w << 16);
+                }
+                group_sync<NT>();
+                const int nx = misc[3];
+                int cached = -1;
+                Box pb = {0.f, 0.f, 0.f, 0.f};
+                bool palive = false;
+                for (int x = wv; x < nx; x += NW) {
+                    const int ent = xlist[x];
+                    const int i = ent & 0xffff;
+                    const int base = (ent >> 16) + (round << 6);
+                    if (base != cached) {
+                        cached = base;
+                        const int pv = base + lane;
+                        const float4 b = sbox[pv];
+                        pb = {b.x, b.y, b.z, b.w};
+                        palive = (alive[pv >> 6] >> (pv & 63)) & 1ull;
+                    }
+                    const float4 mb = sbox[i];
+                    const bool hit = palive && iou_above_band(pb, {mb.x, mb.y, mb.z, mb.w}, xband);
+                    if (__ballot(hit) && lane == 0) {
+                        kills[i] = 0ull;     // kills nobody when its block is walked
+                        atomicAnd(&alive[i >> 6], ~(1ull << (i & 63)));
                     }
                 }
                 group_sync<NT>();
+#pragma unroll
+                for (int e = 0; e < ITEMS; ++e)
+                    if (al[e]) al[e] = (alive[e * NW + wv] >> lane) & 1ull;
             }
         }
         YH_STAMP(14);
