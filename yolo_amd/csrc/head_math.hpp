@@ -133,6 +133,19 @@ __device__ __forceinline__ IouBand make_iou_band(float thr) {
     }
     return b;
 }
+// As iou_above_band below with the two areas (box_area of each box) handed in, for a loop that
+// keeps one box for many tests; a lane that is unsure divides, the others skip the division.
+__device__ __forceinline__ bool iou_above_band_areas(const Box& p, float a1, const Box& g, float a2,
+                                                     const IouBand& band) {
+    const float iw = fmaxf(vmin_raw(p.r, g.r) - vmax_raw(p.l, g.l), 0.0f);
+    const float ih = fmaxf(vmin_raw(p.b, g.b) - vmax_raw(p.t, g.t), 0.0f);
+    const float inter = iw * ih;
+    const float uni = (a1 + a2) - inter;
+    const float q = inter * rcp_fast(uni);
+    bool above = q > band.hi;
+    if (!(q > band.hi) && !(q < band.lo)) above = (uni == 0.0f ? 0.0f : inter / uni) > band.thr;
+    return above;
+}
 __device__ __forceinline__ bool iou_above_band(const Box& p, const Box& g, const IouBand& band) {
     const float a1 = box_area(p);
     const float a2 = box_area(g);

@@ -869,13 +869,15 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             int ii = k - poff[p];                 // earlier member, ii < j
             int nL = sp + L < nvalid ? slen[sp + L] : 0;
             float4 bp = sbox[p];
+            float abp = box_area({bp.x, bp.y, bp.z, bp.w});
             const IouBand band = make_iou_band(a.iou_thr);
             // The loop is bound by instruction issue (the other wavefronts of the SIMD cover
             // the LDS latency; requesting the next pair's boxes ahead of the test was
             // measured slower), so it is written for instruction count.
             for (; k < kend; ++k) {
                 const float4 b = sbox[sp + ii];
-                if (iou_above_band({b.x, b.y, b.z, b.w}, {bp.x, bp.y, bp.z, bp.w}, band))
+                const Box eb{b.x, b.y, b.z, b.w};
+                if (iou_above_band_areas(eb, box_area(eb), {bp.x, bp.y, bp.z, bp.w}, abp, band))
                     atomicOr(&kills[sp + ii], 1ull << j);
                 if (++ii == j) {
                     ii = 0;
@@ -891,6 +893,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                         j = 1;
                     }
                     bp = sbox[sp + j];
+                    abp = box_area({bp.x, bp.y, bp.z, bp.w});
                 }
             }
         }
