@@ -595,18 +595,13 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         group_sync<NT>();
         YH_STAMP(3);
         // exclusive prefix sum over the classes: a contiguous chunk per thread,
-        // shuffle scan per wavefront, carries through LDS
+        // scan per wavefront (DPP), carries through LDS
         const int chunk = (nc + NT - 1) / NT;
         const int cbeg = t * chunk;
         int local = 0;
         for (int q = 0; q < chunk; ++q)
             if (cbeg + q < nc) local += hist[cbeg + q];
-        int incl = local;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int up = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += up;
-        }
+        const int incl = wave_excl_scan(local) + local;
         if (lane == 63) wtot[wv] = incl;
         group_sync<NT>();
         YH_STAMP(4);
@@ -813,29 +808,22 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             // the pair loop and the block lengths go by block starts (this thread alone has
             // read sseg[i] so far)
             if (nrounds > 1 && al[e]) sseg[i] = i - r[e];
-            int incl = r[e];
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int up = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += up;
-            }
-            excl[e] = incl - r[e];
-            if (lane == 63) ctot[e * NW + wv] = incl;
+            excl[e] = wave_excl_scan(r[e]);
+            if (lane == 63) ctot[e * NW + wv] = excl[e] + r[e];
             if (al[e]) kills[i] = 0ull;
         }
         if (t == 0) misc[2] = 0;   // number of block heads queued below
         group_sync<NT>();
         YH_STAMP(9);
-        int npairs = 0;
+        // prefix sums of the chunk totals: a lane per chunk, one scan per wavefront
+        static_assert(ITEMS * NW <= 64, "a lane per chunk of 64 positions");
+        const int wv_s = __builtin_amdgcn_readfirstlane(wv);
+        const int cw = lane < ITEMS * NW ? ctot[lane] : 0;
+        const int cex = wave_excl_scan(cw);
+        const int npairs = __builtin_amdgcn_readlane(cex + cw, ITEMS * NW - 1);
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
-            int carry = 0;
-#pragma unroll
-            for (int q = 0; q < ITEMS * NW; ++q) {
-                const int v = ctot[q];
-                if (q < e * NW + wv) carry += v;
-                npairs += e == 0 ? v : 0;
-            }
+            const int carry = __builtin_amdgcn_readlane(cex, e * NW + wv_s);
             if (al[e]) {
                 const int i = e * NT + t;
                 poff[i] = carry + excl[e];
@@ -993,14 +981,14 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                 mybox[e] = {b.x, b.y, b.z, b.w};
             }
         }
-#pragma unroll
-        for (int w = 0; w < ITEMS * NW; ++w) total += __popcll(alive[w]);
+        // survivors before each chunk of 64 positions: a lane per chunk, one scan per wavefront
+        const int ac = lane < ITEMS * NW ? __popcll(alive[lane]) : 0;
+        const int aex = wave_excl_scan(ac);
+        total = __builtin_amdgcn_readlane(aex + ac, ITEMS * NW - 1);
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
-            const int myw = e * NW + wv;
-            int pos = __popcll(alive[myw] & ((1ull << lane) - 1ull));
-            for (int w = 0; w < myw; ++w) pos += __popcll(alive[w]);
-            pos_out[e] = pos;
+            const int myw = e * NW + wv_s;
+            pos_out[e] = __popcll(alive[myw] & ((1ull << lane) - 1ull)) + __builtin_amdgcn_readlane(aex, myw);
         }
     }
 #ifdef YH_PHASE_PROBE
