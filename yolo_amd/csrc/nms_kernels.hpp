@@ -210,6 +210,12 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         cscore[e] = 0.f; ccl[e] = 0; cidx[e] = 0; cvalid[e] = false;
     }
     if (t == 0) { misc[0] = 0; misc[1] = 0; }
+    if constexpr (kBucket) {
+        // the class histogram starts at zero; with a candidate per predictor the barrier
+        // behind the class argmax orders this before the first count
+        int* hist0 = reinterpret_cast<int*>(region + a.off_hist);
+        for (int c = t; c < a.nc; c += NT) hist0[c] = 0;
+    }
 
     if constexpr (kHead) {
         constexpr bool kStatic = BX_CT > 0 && C_CT > 0;
@@ -587,8 +593,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         int* segst = reinterpret_cast<int*>(region + a.off_segst);  // per class: first sorted position
         int* wtot = misc + 8;                                       // per wavefront: scan carry
         const int nc = a.nc;
-        for (int c = t; c < nc; c += NT) hist[c] = 0;
-        group_sync<NT>();
+        if (a.mode == 0) group_sync<NT>();   // no barrier since the histogram was cleared
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e)
             if (cvalid[e]) atomicAdd(&hist[ccl[e]], 1);
@@ -606,7 +611,12 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         group_sync<NT>();
         YH_STAMP(4);
         int run = incl - local;
-        for (int w = 0; w < wv; ++w) run += wtot[w];
+        {
+            // carries of the wavefronts before mine: a lane per wavefront, one scan
+            static_assert(NW <= 64, "a lane per wavefront");
+            const int wc = lane < NW ? wtot[lane] : 0;
+            run += __builtin_amdgcn_readlane(wave_excl_scan(wc), __builtin_amdgcn_readfirstlane(wv));
+        }
         for (int q = 0; q < chunk; ++q) {
             const int c = cbeg + q;
             if (c < nc) {
