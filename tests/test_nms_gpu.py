@@ -124,6 +124,26 @@ def test_one_class_takes_most_cells(dev, S, Bx, C):
         assert_same(got, oracle_nms(ltrb, score, cls, present, ct, it))
 
 
+@pytest.mark.parametrize("size", [1e-19, 3e-16, 1e-12])
+def test_boxes_whose_areas_are_denormal(dev, size):
+    """Boxes of 1e-19 px have areas of 1e-38, among the denormals, where a product or a
+    reciprocal no longer carries 24 bits: such pairs must take the division."""
+    g = torch.Generator().manual_seed(5)
+    batch, n = 2, 300
+    lt = torch.rand(batch, n, 2, generator=g) * (2 * size)
+    wh = torch.rand(batch, n, 2, generator=g) * (2 * size) + size
+    ltrb = torch.cat([lt, lt + wh], dim=-1).contiguous()
+    score = torch.rand(batch, n, generator=g)
+    cls = torch.randint(0, 3, (batch, n), generator=g, dtype=torch.int32)
+    present = torch.ones(batch, n, dtype=torch.bool)
+    for it in (0.3, 0.5):
+        got = YOLOv1Head.nms(ltrb.to(dev), score.to(dev), cls.to(dev), present.to(dev), 0.0, it,
+                             return_idx=True)
+        want = oracle_nms(ltrb, score, cls, present, 0.0, it)
+        assert 3 < want[1].min() and want[1].max() < n      # some suppressed, some kept
+        assert_same(got, want)
+
+
 def test_iou_threshold_on_and_next_to_a_pair_iou(dev):
     """The workgroup-per-image kernel decides IoU > threshold without dividing;
     thresholds that ARE the IoU of some pair, and the floats next to it on either

@@ -116,12 +116,12 @@ __device__ __forceinline__ float iou_pair(const Box& p, const Box& g) {
     return uni == 0.0f ? 0.0f : inter / uni;
 }
 
-// "iou_pair(p, g) > thr" for a wavefront: the quotient formed with v_rcp_f32 is
-// within 3e-7 relative of the correctly rounded one, so outside the band
-// [lo, hi] = thr * (1 -+ 2e-6) it decides; a lane inside the band (or with a
-// NaN from 0 * inf) takes the IEEE division, and the wavefront skips that code
-// unless one of its lanes needs it.  thr <= 0 or not finite: lo = -inf,
-// hi = +inf, every lane divides.  Same answer as iou_pair(...) > thr, always.
+// "iou_pair(p, g) > thr" without the division where that is safe: outside the band
+// [lo, hi] = thr * (1 -+ 2e-6) the products lo * union and hi * union decide (each is
+// rounded once, 6e-8 relative, far inside the band); a lane inside the band, or with a
+// union of zero or near the denormals, takes the IEEE division.  thr <= 0 or not
+// finite: lo = -inf, hi = +inf, every lane divides.  Same answer as iou_pair(...) > thr,
+// always.
 struct IouBand {
     float thr, lo, hi;
 };
@@ -141,25 +141,19 @@ __device__ __forceinline__ bool iou_above_band_areas(const Box& p, float a1, con
     const float ih = fmaxf(vmin_raw(p.b, g.b) - vmax_raw(p.t, g.t), 0.0f);
     const float inter = iw * ih;
     const float uni = (a1 + a2) - inter;
-    const float q = inter * rcp_fast(uni);
-    bool above = q > band.hi;
-    if (!(q > band.hi) && !(q < band.lo)) above = (uni == 0.0f ? 0.0f : inter / uni) > band.thr;
+    // inter > hi * uni (rounded once, 6e-8 relative) puts the quotient above thr with room to
+    // spare, inter < lo * uni below it.  The 1e-30 added on either side widens the band by
+    // nothing for boxes of ordinary size and keeps a union of zero or near the denormals
+    // (boxes of 1e-15 px, where a product no longer carries 24 bits) inside it; so does a
+    // band of +-inf.  A lane inside the band divides.
+    const float t_hi = __builtin_fmaf(band.hi, uni, 1e-30f);
+    const float t_lo = __builtin_fmaf(band.lo, uni, -1e-30f);
+    bool above = inter > t_hi;
+    if (!(inter > t_hi) && !(inter < t_lo)) above = (uni == 0.0f ? 0.0f : inter / uni) > band.thr;
     return above;
 }
 __device__ __forceinline__ bool iou_above_band(const Box& p, const Box& g, const IouBand& band) {
-    const float a1 = box_area(p);
-    const float a2 = box_area(g);
-    const float iw = fmaxf(vmin_raw(p.r, g.r) - vmax_raw(p.l, g.l), 0.0f);
-    const float ih = fmaxf(vmin_raw(p.b, g.b) - vmax_raw(p.t, g.t), 0.0f);
-    const float inter = iw * ih;
-    const float uni = (a1 + a2) - inter;
-    const float q = inter * rcp_fast(uni);
-    bool above = q > band.hi;
-    const bool unsure = !(q > band.hi) && !(q < band.lo);
-    if (__ballot(unsure)) {
-        if (unsure) above = (uni == 0.0f ? 0.0f : inter / uni) > band.thr;
-    }
-    return above;
+    return iou_above_band_areas(p, box_area(p), g, box_area(g), band);
 }
 
 // share of the gradient that max(a, b) (or min) sends to a: all of it when a
