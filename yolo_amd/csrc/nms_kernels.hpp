@@ -599,31 +599,43 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             if (cvalid[e]) atomicAdd(&hist[ccl[e]], 1);
         group_sync<NT>();
         YH_STAMP(3);
-        // exclusive prefix sum over the classes: a contiguous chunk per thread,
-        // scan per wavefront (DPP), carries through LDS
-        const int chunk = (nc + NT - 1) / NT;
-        const int cbeg = t * chunk;
-        int local = 0;
-        for (int q = 0; q < chunk; ++q)
-            if (cbeg + q < nc) local += hist[cbeg + q];
-        const int incl = wave_excl_scan(local) + local;
-        if (lane == 63) wtot[wv] = incl;
-        group_sync<NT>();
-        YH_STAMP(4);
-        int run = incl - local;
-        {
-            // carries of the wavefronts before mine: a lane per wavefront, one scan
-            static_assert(NW <= 64, "a lane per wavefront");
-            const int wc = lane < NW ? wtot[lane] : 0;
-            run += __builtin_amdgcn_readlane(wave_excl_scan(wc), __builtin_amdgcn_readfirstlane(wv));
-        }
-        for (int q = 0; q < chunk; ++q) {
-            const int c = cbeg + q;
-            if (c < nc) {
-                const int h = hist[c];
-                segst[c] = run;
-                run += h;
-                hist[c] = 0;   // becomes the fill cursor of the bucket
+        // exclusive prefix sum over the classes
+        if (nc <= 128) {
+            // two classes per lane: the first wavefront does it alone, no carries, one barrier less
+            if (wv == 0) {
+                const int h0 = lane < nc ? hist[lane] : 0;
+                const int h1 = 64 + lane < nc ? hist[64 + lane] : 0;
+                const int e0 = wave_excl_scan(h0);
+                const int e1 = wave_excl_scan(h1) + __builtin_amdgcn_readlane(e0 + h0, 63);
+                if (lane < nc) { segst[lane] = e0; hist[lane] = 0; }              // the count becomes
+                if (64 + lane < nc) { segst[64 + lane] = e1; hist[64 + lane] = 0; }   // the bucket's fill cursor
+            }
+        } else {
+            // a contiguous chunk of classes per thread, scan per wavefront (DPP), carries through LDS
+            const int chunk = (nc + NT - 1) / NT;
+            const int cbeg = t * chunk;
+            int local = 0;
+            for (int q = 0; q < chunk; ++q)
+                if (cbeg + q < nc) local += hist[cbeg + q];
+            const int incl = wave_excl_scan(local) + local;
+            if (lane == 63) wtot[wv] = incl;
+            group_sync<NT>();
+            YH_STAMP(4);
+            int run = incl - local;
+            {
+                // carries of the wavefronts before mine: a lane per wavefront, one scan
+                static_assert(NW <= 64, "a lane per wavefront");
+                const int wc = lane < NW ? wtot[lane] : 0;
+                run += __builtin_amdgcn_readlane(wave_excl_scan(wc), __builtin_amdgcn_readfirstlane(wv));
+            }
+            for (int q = 0; q < chunk; ++q) {
+                const int c = cbeg + q;
+                if (c < nc) {
+                    const int h = hist[c];
+                    segst[c] = run;
+                    run += h;
+                    hist[c] = 0;   // becomes the fill cursor of the bucket
+                }
             }
         }
         group_sync<NT>();
