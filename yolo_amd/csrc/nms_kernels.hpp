@@ -610,6 +610,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                 if (lane < nc) { segst[lane] = e0; hist[lane] = 0; }              // the count becomes
                 if (64 + lane < nc) { segst[64 + lane] = e1; hist[64 + lane] = 0; }   // the bucket's fill cursor
             }
+            YH_STAMP(4);
         } else {
             // a contiguous chunk of classes per thread, scan per wavefront (DPP), carries through LDS
             const int chunk = (nc + NT - 1) / NT;
