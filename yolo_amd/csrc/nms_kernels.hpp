@@ -191,7 +191,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
     int2* smeta = reinterpret_cast<int2*>(region + a.off_meta);
     int* sseg = reinterpret_cast<int*>(region + a.off_seg);
     unsigned long long* alive = reinterpret_cast<unsigned long long*>(region + a.off_alive);
-    int* misc = reinterpret_cast<int*>(region + a.off_misc);  // [0] valid count, [1] max pos, [4..7] scan carries
+    int* misc = reinterpret_cast<int*>(region + a.off_misc);  // [0] valid count, [1] largest position in a segment, [2] block heads queued, [3] members queued in a round; from [8]: scan carries
     int* ccls = reinterpret_cast<int*>(region + a.off_ccls);
 
     const int nslot = a.nslot;
