@@ -210,6 +210,10 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         cscore[e] = 0.f; ccl[e] = 0; cidx[e] = 0; cvalid[e] = false;
     }
     if (t == 0) { misc[0] = 0; misc[1] = 0; }
+    if constexpr (!kWave) {
+        // bins and cursors of the pair phase's row sort (the tables of the one-wavefront path lie here)
+        if (t < 160) reinterpret_cast<int*>(region + a.off_kill)[t] = 0;
+    }
     if constexpr (kBucket) {
         // the class histogram starts at zero; with a candidate per predictor the barrier
         // behind the class argmax orders this before the first count
@@ -813,14 +817,19 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         // nobody when its block is walked).  Most images need one round.
         const int nrounds = (maxpos >> 6) + 1;
         unsigned long long* kills = keys;     // the keys are not needed any more
-        // pairs before position p; the array takes the place of smeta, which every
-        // thread has read into registers before the barrier below
-        int* poff = reinterpret_cast<int*>(region + a.off_pair);
-        int* slen = poff + NT * ITEMS;        // at a block's first position: its member count
-        // pairs per chunk of 64, in the liveness words (not written before the greedy pass):
-        // this array is filled before the barrier, so it must not overlap smeta
-        int* ctot = reinterpret_cast<int*>(alive);
-        int r[ITEMS], excl[ITEMS];
+        // The pair phase works on ROWS: a later member p of a block against its r earlier
+        // members, up to 16 of them in a pass (a member with more has its row in several
+        // passes).  The rows are sorted by falling r (a counting sort over the 63 lengths) and
+        // the wavefronts draw them 64 at a time from a queue, the first pass first and the long
+        // rows first: the lanes of a wavefront hold rows of nearly the same length, walk them
+        // in step (next earlier member: an address increment) and leave the loop together,
+        // and no wavefront is left with the long rows.  The row list takes the place of
+        // smeta, which every thread has read into registers before the barrier below.
+        int* rowlist = reinterpret_cast<int*>(region + a.off_pair);
+        int* slen = rowlist + NT * ITEMS;     // at a block's first position: its member count
+        // [0..63] rows of length 63 - bin, [64..127] fill cursors, [128] queue head; cleared at entry
+        int* rowhist = reinterpret_cast<int*>(region + a.off_kill);
+        int r[ITEMS];
         // my block of the segment, and its first position (i - r[e])
         auto blk = [&](int e) { return (e * NT + t - r[e] - mymeta[e].w) >> 6; };
 #pragma unroll
@@ -828,28 +837,24 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             const int i = e * NT + t;
             const int pos = al[e] ? i - mymeta[e].w : 0;
             r[e] = pos & 63;                      // members of my block ahead of me
-            // the pair loop and the block lengths go by block starts (this thread alone has
-            // read sseg[i] so far)
+            // the block lengths go by block starts (this thread alone has read sseg[i] so far)
             if (nrounds > 1 && al[e]) sseg[i] = i - r[e];
-            excl[e] = wave_excl_scan(r[e]);
-            if (lane == 63) ctot[e * NW + wv] = excl[e] + r[e];
             if (al[e]) kills[i] = 0ull;
+            if (r[e] > 0) atomicAdd(&rowhist[63 - r[e]], 1);
         }
         if (t == 0) misc[2] = 0;   // number of block heads queued below
         group_sync<NT>();
         YH_STAMP(9);
-        // prefix sums of the chunk totals: a lane per chunk, one scan per wavefront
-        static_assert(ITEMS * NW <= 64, "a lane per chunk of 64 positions");
         const int wv_s = __builtin_amdgcn_readfirstlane(wv);
-        const int cw = lane < ITEMS * NW ? ctot[lane] : 0;
-        const int cex = wave_excl_scan(cw);
-        const int npairs = __builtin_amdgcn_readlane(cex + cw, ITEMS * NW - 1);
+        // every wavefront scans the 64 bins for itself: no barrier between scan and scatter
+        const int hv = rowhist[lane];
+        const int hex = wave_excl_scan(hv);
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
-            const int carry = __builtin_amdgcn_readlane(cex, e * NW + wv_s);
+            const int i = e * NT + t;
+            const int first = __shfl(hex, 63 - r[e], 64);     // all lanes take part
+            if (r[e] > 0) rowlist[first + atomicAdd(&rowhist[64 + 63 - r[e]], 1)] = i | (r[e] << 16);
             if (al[e]) {
-                const int i = e * NT + t;
-                poff[i] = carry + excl[e];
                 const int nxt = i + 1 < nvalid ? sseg[i + 1] : -1;
                 if (nxt != i - r[e]) slen[i - r[e]] = r[e] + 1;   // the block's last member
             }
@@ -859,52 +864,38 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
 #ifdef YH_PHASE_PROBE
         if (a.dbg_stop == 5) return;
 #endif
-        const int per = (npairs + NT - 1) / NT;
-        int k = t * per;
-        const int kend = min(npairs, k + per);
-        if (k < kend) {
-            // last position whose offset is <= k: the later member of pair k
-            int lo = 0, hi = nvalid - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (poff[mid] <= k) lo = mid; else hi = mid - 1;
-            }
-            // Pairs are numbered by later member, then by earlier member, so inside a
-            // block of L members the walk is register arithmetic: (ii, j) -> (ii + 1, j)
-            // -> ... -> (0, j + 1); the next block starts at sp + L, and its length is
-            // fetched one block ahead.
-            const int p = lo;
-            int sp = sseg[p];                     // first position of the block
-            int L = slen[sp];
-            int j = p - sp;                       // later member, as an index into the block
-            int ii = k - poff[p];                 // earlier member, ii < j
-            int nL = sp + L < nvalid ? slen[sp + L] : 0;
-            float4 bp = sbox[p];
-            float abp = box_area({bp.x, bp.y, bp.z, bp.w});
+        {
             const IouBand band = make_iou_band(a.iou_thr);
-            // The loop is bound by instruction issue (the other wavefronts of the SIMD cover
-            // the LDS latency; requesting the next pair's boxes ahead of the test was
-            // measured slower), so it is written for instruction count.
-            for (; k < kend; ++k) {
-                const float4 b = sbox[sp + ii];
-                const Box eb{b.x, b.y, b.z, b.w};
-                if (iou_above_band_areas(eb, box_area(eb), {bp.x, bp.y, bp.z, bp.w}, abp, band))
-                    atomicOr(&kills[sp + ii], 1ull << j);
-                if (++ii == j) {
-                    ii = 0;
-                    if (++j == L) {
-                        if (k + 1 >= kend) break;
-                        // a later pair exists, so a later block has two members or more;
-                        // one-member blocks are stepped over
-                        do {
-                            sp += L;
-                            L = nL;
-                            nL = sp + L < nvalid ? slen[sp + L] : 0;
-                        } while (L == 1);
-                        j = 1;
+            // rows in pass 0 (all), 1 (longer than 16), 2 (longer than 32), 3 (longer than 48):
+            // each a prefix of the sorted list; and the groups of 64 each pass has
+            const int n0 = __builtin_amdgcn_readlane(hex + hv, 63), n1 = __builtin_amdgcn_readlane(hex, 47);
+            const int n2 = __builtin_amdgcn_readlane(hex, 31), n3 = __builtin_amdgcn_readlane(hex, 15);
+            const int g0 = (n0 + 63) >> 6, g1 = (n1 + 63) >> 6, g2 = (n2 + 63) >> 6, g3 = (n3 + 63) >> 6;
+            for (;;) {
+                int q = 0;
+                if (lane == 0) q = atomicAdd(&rowhist[128], 1);
+                q = __builtin_amdgcn_readfirstlane(q);
+                int pass = 0, n = n0;
+                if (q >= g0) { q -= g0; pass = 1; n = n1; }
+                if (pass == 1 && q >= g1) { q -= g1; pass = 2; n = n2; }
+                if (pass == 2 && q >= g2) { q -= g2; pass = 3; n = n3; }
+                if (pass == 3 && q >= g3) break;
+                const int w = (q << 6) + lane;
+                if (w < n) {
+                    const int ent = rowlist[w];
+                    const int p = ent & 0xffff, rp = ent >> 16;
+                    const int len = min(rp - 16 * pass, 16);
+                    const float4 bp = sbox[p];
+                    const Box later{bp.x, bp.y, bp.z, bp.w};
+                    const float abp = box_area(later);
+                    const unsigned long long jbit = 1ull << rp;
+                    const int base = p - rp + 16 * pass;
+                    for (int ii = 0; ii < len; ++ii) {
+                        const float4 b = sbox[base + ii];
+                        const Box eb{b.x, b.y, b.z, b.w};
+                        if (iou_above_band_areas(eb, box_area(eb), later, abp, band))
+                            atomicOr(&kills[base + ii], jbit);
                     }
-                    bp = sbox[sp + j];
-                    abp = box_area({bp.x, bp.y, bp.z, bp.w});
                 }
             }
         }
@@ -915,7 +906,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
 #endif
         // the block heads queue up in a list (any order: blocks of one round are
         // independent), each with its block number; the pair offsets are dead by now
-        int* hlist = poff;
+        int* hlist = rowlist;
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
             const int i = e * NT + t;
