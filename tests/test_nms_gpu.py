@@ -251,6 +251,35 @@ def test_fused_decode_nms(dev, S, Bx, C, batch, mode, ct, it):
     assert_same(got2, oracle_nms(ltrb, score, cls, present, ct, it))
 
 
+@pytest.mark.parametrize("S,Bx,C,mode", [
+    (7, 2, 20, MODE_DENSE),      # the headline shape with a candidate per predictor (98 slots)
+    (8, 2, 64, MODE_DENSE),      # all 128 slots, the largest class table of the path without a sort
+    (8, 2, 65, MODE_DENSE),      # one class more: the ranked path
+    (8, 2, 1, MODE_DENSE),       # one class of up to 128 members: the masks' second word, long kill chains
+    (9, 1, 3, MODE_REFERENCE),   # 81 slots, a candidate per cell
+    (6, 3, 20, MODE_DENSE),      # 108 slots, three predictors of a cell in one class
+    (5, 3, 7, MODE_DENSE),       # 75 slots
+])
+@pytest.mark.parametrize("ct,it", [(0.0, 0.5), (0.3, 0.05), (0.5, 0.7)])
+def test_two_candidates_per_lane(dev, S, Bx, C, mode, ct, it):
+    """65 to 128 slots per image: one wavefront holds two candidates per lane and 128-bit
+    lane masks in two words.  Random heads, heads whose boxes crowd (many IoUs above the
+    threshold) and heads with equal scores, channel-major and cell-major, against the oracle."""
+    head = YOLOv1Head(img_size=32 * S, n_cells=S, n_bboxes=Bx, n_classes=C)
+    for variant in range(3):
+        pred = synth.make_pred(9, S, Bx, C, seed=1000 * S + 10 * Bx + variant)
+        if variant == 1:      # wide boxes: most pairs of a class overlap
+            pred[:, [5 * k + q for k in range(Bx) for q in (2, 3)]] += 2.0
+        if variant == 2:      # equal confidences: the order falls back to the flat index
+            pred[:, [5 * k + 4 for k in range(Bx)]] = pred[:, [5 * k + 4 for k in range(Bx)]].round()
+        pred = pred.to(dev)
+        ltrb, score, cls, present = head.decode_candidates(pred, mode)
+        want = oracle_nms(ltrb, score, cls, present, ct, it)
+        assert_same(head.postprocess(pred, ct, it, mode, return_idx=True), want)
+        nhwc = pred.contiguous(memory_format=torch.channels_last)
+        assert_same(head.postprocess(nhwc, ct, it, mode, return_idx=True), want)
+
+
 def test_config1_against_full_cpu_path(dev, golden):
     """Whole inference path, CPU decode included, at config 1.  On this seed no
     tie case occurs, so the keep sets agree exactly; box values agree to the

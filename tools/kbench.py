@@ -12,6 +12,7 @@ ws = head._get_workspace(dev, lib.yh_workspace_bytes(0, B, 7, 2, 20))
 grad = torch.empty_like(pred); om8 = om.view(torch.uint8)
 dets = torch.empty(B, 98, 6, device=dev); cnt = torch.empty(B, dtype=torch.int32, device=dev); terms = torch.empty(5, device=dev)
 mode = int(os.environ.get("KB_MODE", "0"))
+conf = float(os.environ.get("KB_CONF", "0.5"))
 def k_loss(): lib.yh_loss_partials(pred.data_ptr(), gx.data_ptr(), gc.data_ptr(), om8.data_ptr(), grad.data_ptr(), ws.data_ptr(), ws.numel(), B, 7, 2, 20, 448, 5.0, 0.5, 1.0 / B, st)
 from yolo_amd import LossLog
 plog = LossLog(dev, 64)
@@ -22,7 +23,7 @@ def k_pipe():
     lib.yh_loss_fwd_bwd_pipelined(pred.data_ptr(), gx.data_ptr(), gc.data_ptr(), om8.data_ptr(), grad.data_ptr(), None, plog.ring.data_ptr(), 64, plog.cursor.data_ptr(), wsp.data_ptr(), wsp.numel(), ph[0], B, 7, 2, 20, 448, 5.0, 0.5, 1.0 / B, st)
 def k_two(): k_loss(); k_fin()
 def k_fin(): lib.yh_loss_finalize(ws.data_ptr(), ws.numel(), B, 7, 1.0 / B, terms.data_ptr(), None, 0, None, st)
-def k_nms(): lib.yh_decode_nms(pred.data_ptr(), dets.data_ptr(), cnt.data_ptr(), None, mode, 0.5, 0.5, B, 7, 2, 20, 448, st)
+def k_nms(): lib.yh_decode_nms(pred.data_ptr(), dets.data_ptr(), cnt.data_ptr(), None, mode, conf, 0.5, B, 7, 2, 20, 448, st)
 def b2b(fn, iters=300):
     for _ in range(200): fn()
     torch.cuda.synchronize()

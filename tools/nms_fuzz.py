@@ -4,6 +4,7 @@ device decoded (the comparison tests/test_nms_gpu.py::test_fused_decode_nms make
 fixed list).  A development aid for changes to nms_kernels.hpp; the oracle is the checker.
 
     python tools/nms_fuzz.py [configs] [seed]
+    NF_SLOTS=65,128 python tools/nms_fuzz.py 500     (slot counts of one kernel variant only)
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,12 +16,14 @@ from yolo_amd import MODE_DENSE, MODE_REFERENCE, YOLOv1Head, synth
 dev = torch.device("cuda:0")
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+# NF_SLOTS="65,128" keeps the slot count S*S*Bx of every config inside that range
+SLOT_LO, SLOT_HI = (int(v) for v in os.environ.get("NF_SLOTS", "1,2048").split(","))
 t_start = time.time()
 longest = most = 0      # longest class segment and most candidates of an image so far
 for it_no in range(n_cfg):
     while True:
         S = int(rng.integers(1, 21)); Bx = int(rng.integers(1, 6)); C = int(rng.choice([1, 2, 3, 7, 20, 33, 80, 100]))
-        if S * S * Bx <= 2048:
+        if SLOT_LO <= S * S * Bx <= SLOT_HI:
             break
     batch = int(rng.integers(1, 4))
     mode = MODE_DENSE if rng.random() < 0.7 else MODE_REFERENCE

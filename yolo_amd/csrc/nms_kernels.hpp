@@ -326,7 +326,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         } else {
             // slot = cell*nb + k; the class is computed once per cell
             constexpr bool kSplit = kStatic && NT >= 2 * (S_CT * S_CT) && C_CT >= 32 && C_CT % 16 == 0;
-            float blog[ITEMS][5];     // kSplit: the candidates' own logits, requested early
+            float blog[ITEMS][5];     // kStatic: the candidates' own logits, requested early
             if constexpr (kSplit) {
                 // More threads than cells: a cell's classes are shared out in slices of 16, a
                 // (slice, cell) pair per work item, every item's 16 logits requested before
@@ -394,7 +394,25 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                     }
                     ccls[t] = best;
                 }
-            } else
+            } else {
+            if constexpr (kStatic) {
+                // the candidates' own logits are requested together with the class logits:
+                // one round trip to memory instead of two
+#pragma unroll
+                for (int e = 0; e < ITEMS; ++e) {
+                    const int n = e * NT + t;
+                    const int cell = n < nslot ? n / BX_CT : 0;
+                    const int k = n < nslot ? n - cell * BX_CT : 0;
+                    const float* q = pimg + cell + (size_t)(5 * k) * S2;
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) blog[e][u] = q[u * S2];
+                    if constexpr (kBias) {
+                        const float* bq = a.bias + cell + (size_t)(5 * k) * S2;
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) blog[e][u] += bq[u * S2];
+                    }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < ITEMS; ++e) {   // S*S <= nslot <= NT*ITEMS
                 const int cell = e * NT + t;
@@ -416,6 +434,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                         MemLogitsT<kBias>{p, kBias ? a.bias + cell : nullptr, chs}, 5 * nb, nc);
                 }
             }
+            }
             group_sync<NT>();
             YH_STAMP(1);
 #pragma unroll
@@ -427,7 +446,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                     const MemLogitsT<kBias> q{pimg + cell * cells + (5 * k) * chs,
                                               kBias ? a.bias + cell + (5 * k) * S2 : nullptr, chs};
                     float lx, ly, lw, lh, lc;
-                    if constexpr (kSplit) {
+                    if constexpr (kStatic) {
                         lx = blog[e][0]; ly = blog[e][1]; lw = blog[e][2]; lh = blog[e][3]; lc = blog[e][4];
                     } else {
                         lx = q(0); ly = q(1); lw = q(2); lh = q(3); lc = q(4);
@@ -543,6 +562,129 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                 store_stream(row + 1, make_float2(cbox[0].r, cbox[0].b));
                 store_stream(row + 2, make_float2(cscore[0], (float)ccl[0]));
                 if (kd) kd[pos] = cidx[0];
+            }
+            for (int i = total * 3 + t; i < nout * 3; i += NT) store_stream(dst2 + i, make_float2(0.0f, 0.0f));
+            if (kd)
+                for (int i = total + t; i < nout; i += NT) kd[i] = -1;
+            if (t == 0) a.keep_count[img] = total;
+            YH_STAMP(15);
+            return;
+        }
+    }
+
+    // The same without a sort for two candidates per lane (65 to 128 slots, e.g. a
+    // candidate per predictor at S=7, Bx=2): slot s = e*64 + lane, every lane mask is
+    // 128 bits in two words (word s >> 6, bit s & 63), the class table holds two words
+    // per class and the kill / precedence tables two words per slot.
+    if constexpr (kWave && ITEMS == 2 && kHead) {
+        const int nc_tab = C_CT > 0 ? C_CT : a.nc;
+        if (nc_tab <= 64) {
+            unsigned long long* killt = reinterpret_cast<unsigned long long*>(region + a.off_kill);
+            unsigned long long* hight = killt + 256;
+            float* sscore = reinterpret_cast<float*>(smeta);
+            YH_STAMP(2);
+            const unsigned long long me = 1ull << lane;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int s = e * 64 + lane;
+                keys[s] = 0ull;
+                killt[2 * s] = 0ull; killt[2 * s + 1] = 0ull;
+                hight[2 * s] = 0ull; hight[2 * s + 1] = 0ull;
+                sbox[s] = make_float4(cbox[e].l, cbox[e].t, cbox[e].r, cbox[e].b);
+                sscore[s] = cscore[e];
+            }
+            group_sync<NT>();
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (cvalid[e]) atomicOr(&keys[2 * ccl[e] + e], me);
+            group_sync<NT>();
+            int h[2];
+            unsigned long long rlo[2], rhi[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int s = e * 64 + lane;
+                const unsigned long long m0 = cvalid[e] ? keys[2 * ccl[e]] : 0ull;
+                const unsigned long long m1 = cvalid[e] ? keys[2 * ccl[e] + 1] : 0ull;
+                const int n = __popcll(m0) + __popcll(m1);
+                const int p = e == 0 ? __popcll(m0 & (me - 1ull)) : __popcll(m0) + __popcll(m1 & (me - 1ull));
+                h[e] = (n - 1) >> 1;                    // -1 for a slot without a candidate
+                if (n > 0 && (n & 1) == 0 && p < (n >> 1)) ++h[e];
+                // bit k of the rotated mask is slot (s + 1 + k) & 127: the members after this one, cyclically
+                const int sh = (s + 1) & 127;
+                const unsigned long long lo = sh >= 64 ? m1 : m0, hi = sh >= 64 ? m0 : m1;
+                const int r = sh & 63;
+                rlo[e] = r ? (lo >> r) | (hi << (64 - r)) : lo;
+                rhi[e] = r ? (hi >> r) | (lo << (64 - r)) : hi;
+            }
+            const IouBand band = make_iou_band(a.iou_thr);
+            while (__ballot(h[0] > 0 || h[1] > 0)) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if (h[e] > 0) {
+                        --h[e];
+                        int k1;                          // distance to the next member, 1-based
+                        if (rlo[e]) { k1 = __ffsll((long long)rlo[e]); rlo[e] &= rlo[e] - 1ull; }
+                        else { k1 = 64 + __ffsll((long long)rhi[e]); rhi[e] &= rhi[e] - 1ull; }
+                        const int s = e * 64 + lane;
+                        const int j = (s + k1) & 127;
+                        const float sj = sscore[j];
+                        const float4 b = sbox[j];
+                        const bool j_first = sj > cscore[e] || (sj == cscore[e] && j < s);
+                        const int later = j_first ? s : j;
+                        const int first = j_first ? j : s;
+                        const unsigned long long first_bit = 1ull << (first & 63);
+                        atomicOr(&hight[2 * later + (first >> 6)], first_bit);
+                        if (iou_above_band({b.x, b.y, b.z, b.w}, cbox[e], band))
+                            atomicOr(&killt[2 * later + (first >> 6)], first_bit);
+                    }
+                }
+            }
+            group_sync<NT>();
+            YH_STAMP(3);
+            unsigned long long kl[2][2], hg[2][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int s = e * 64 + lane;
+                kl[e][0] = killt[2 * s]; kl[e][1] = killt[2 * s + 1];
+                hg[e][0] = hight[2 * s]; hg[e][1] = hight[2 * s + 1];
+            }
+            unsigned long long und[2] = {__ballot(cvalid[0]), __ballot(cvalid[1])};
+            unsigned long long kept[2] = {0ull, 0ull};
+            while (und[0] | und[1]) {
+                bool keep[2], die[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const bool u = (und[e] >> lane) & 1ull;
+                    die[e] = u && ((kl[e][0] & kept[0]) | (kl[e][1] & kept[1])) != 0ull;
+                    keep[e] = u && !die[e] && ((kl[e][0] & und[0]) | (kl[e][1] & und[1])) == 0ull;
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const unsigned long long km = __ballot(keep[e]);
+                    kept[e] |= km;
+                    und[e] &= ~(km | __ballot(die[e]));
+                }
+            }
+            YH_STAMP(4);
+            // kept slots per class -> first output row of each class
+            int* cbase = sseg;
+            cbase[lane] = wave_excl_scan(
+                lane < nc_tab ? __popcll(keys[2 * lane] & kept[0]) + __popcll(keys[2 * lane + 1] & kept[1]) : 0);
+            group_sync<NT>();
+            const int total = __popcll(kept[0]) + __popcll(kept[1]);
+            const int nout = a.nout;
+            float2* dst2 = reinterpret_cast<float2*>(a.dets + img * (long long)nout * 6);
+            int32_t* kd = a.keep_idx ? a.keep_idx + img * (long long)nout : nullptr;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if ((kept[e] >> lane) & 1ull) {
+                    const int pos = cbase[ccl[e]] + __popcll(hg[e][0] & kept[0]) + __popcll(hg[e][1] & kept[1]);
+                    float2* row = dst2 + pos * 3;
+                    store_stream(row + 0, make_float2(cbox[e].l, cbox[e].t));
+                    store_stream(row + 1, make_float2(cbox[e].r, cbox[e].b));
+                    store_stream(row + 2, make_float2(cscore[e], (float)ccl[e]));
+                    if (kd) kd[pos] = cidx[e];
+                }
             }
             for (int i = total * 3 + t; i < nout * 3; i += NT) store_stream(dst2 + i, make_float2(0.0f, 0.0f));
             if (kd)

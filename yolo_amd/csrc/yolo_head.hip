@@ -85,8 +85,9 @@ void nms_layout(yh::NmsArgs& a, int slot_pad, int imgs_per_block = 1) {
     // the 2 * slot_pad ints at off_meta, which are dead by then
     a.off_pair = a.off_meta;
     // kill and precedence tables of the one-wavefront path: 2 x 64 words of 64 bits
+    // (2 x 128 slots x 2 words with two candidates per lane)
     a.off_kill = off;
-    off += 1024;
+    off += slot_pad == 128 ? 4096 : 1024;
     // a cell-major image is staged through LDS when the blocks of a workgroup's images are
     // small enough to leave room for a second workgroup on the CU
     a.off_stage = -1;
