@@ -280,6 +280,33 @@ def test_two_candidates_per_lane(dev, S, Bx, C, mode, ct, it):
         assert_same(head.postprocess(nhwc, ct, it, mode, return_idx=True), want)
 
 
+@pytest.mark.parametrize("S,Bx,C,mode", [
+    (7, 2, 80, MODE_REFERENCE),   # 49 slots, 80 classes: two classes per lane in the class scan
+    (8, 1, 128, MODE_DENSE),      # 64 slots, the largest class table without a sort
+    (8, 1, 129, MODE_DENSE),      # one class more: the ranked path
+    (7, 2, 65, MODE_REFERENCE),
+    (5, 2, 100, MODE_DENSE),      # 50 slots
+])
+@pytest.mark.parametrize("ct,it", [(0.0, 0.5), (0.3, 0.05), (0.5, 0.7)])
+def test_one_candidate_per_lane_with_more_than_64_classes(dev, S, Bx, C, mode, ct, it):
+    """At most 64 slots and 65 to 128 classes: the class -> lane-mask table no longer fits the
+    key array and the per-class row offsets are scanned two classes per lane."""
+    head = YOLOv1Head(img_size=32 * S, n_cells=S, n_bboxes=Bx, n_classes=C)
+    for variant in range(3):
+        pred = synth.make_pred(9, S, Bx, C, seed=2000 * S + 10 * Bx + variant)
+        if variant == 1:      # the upper classes win most cells, boxes crowd
+            pred[:, 5 * Bx + C - 3:] += 3.0
+            pred[:, [5 * k + q for k in range(Bx) for q in (2, 3)]] += 2.0
+        if variant == 2:      # equal confidences
+            pred[:, [5 * k + 4 for k in range(Bx)]] = pred[:, [5 * k + 4 for k in range(Bx)]].round()
+        pred = pred.to(dev)
+        ltrb, score, cls, present = head.decode_candidates(pred, mode)
+        want = oracle_nms(ltrb, score, cls, present, ct, it)
+        assert_same(head.postprocess(pred, ct, it, mode, return_idx=True), want)
+        nhwc = pred.contiguous(memory_format=torch.channels_last)
+        assert_same(head.postprocess(nhwc, ct, it, mode, return_idx=True), want)
+
+
 def test_config1_against_full_cpu_path(dev, golden):
     """Whole inference path, CPU decode included, at config 1.  On this seed no
     tie case occurs, so the keep sets agree exactly; box values agree to the

@@ -479,8 +479,8 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
 #ifdef YH_PHASE_PROBE
     if (a.dbg_stop == 1) { if (cvalid[0] && cscore[0] == 12345.f) a.keep_count[img] = ccl[0] + (int)cbox[0].l; return; }
 #endif
-    // One wavefront per image, one candidate per lane, classes that fit a 64-entry
-    // table: no sort.  The lanes of a class find each other through a class -> lane
+    // One wavefront per image, one candidate per lane, at most 128 classes: no sort.
+    // The lanes of a class find each other through a class -> lane
     // mask table in LDS (one 64-bit OR per lane).  Every pair of a class is then
     // looked at once, the pairs of a class of n spread evenly over its members: a
     // member takes the (n-1)/2 members that follow it cyclically in lane order (one
@@ -494,7 +494,12 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
     // mask table, prefix-summed across lanes) plus the kept lanes in `higher`.
     if constexpr (kWave && ITEMS == 1 && kHead) {
         const int nc_tab = C_CT > 0 ? C_CT : a.nc;
-        if (nc_tab <= 64) {
+        if (nc_tab <= 128) {
+            // the class -> lane-mask table: the key array for up to 64 classes, else the
+            // (adjacent) histogram and bucket-start arrays, 2 x 4 bytes per class
+            const bool small = nc_tab <= 64;
+            unsigned long long* cmask =
+                small ? keys : reinterpret_cast<unsigned long long*>(region + a.off_hist);
             unsigned long long* killt = reinterpret_cast<unsigned long long*>(region + a.off_kill);
             unsigned long long* hight = killt + 64;
             float* sscore = reinterpret_cast<float*>(smeta);
@@ -502,15 +507,16 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             const unsigned long long me = 1ull << lane;
             const bool valid = cvalid[0];
             const float myscore = cscore[0];
-            keys[lane] = 0ull;
+            cmask[lane] = 0ull;
+            if (!small) cmask[lane + 64] = 0ull;
             killt[lane] = 0ull;
             hight[lane] = 0ull;
             sbox[lane] = make_float4(cbox[0].l, cbox[0].t, cbox[0].r, cbox[0].b);
             sscore[lane] = myscore;
             group_sync<NT>();
-            if (valid) atomicOr(&keys[ccl[0]], me);
+            if (valid) atomicOr(&cmask[ccl[0]], me);
             group_sync<NT>();
-            const unsigned long long mine = valid ? keys[ccl[0]] : 0ull;
+            const unsigned long long mine = valid ? cmask[ccl[0]] : 0ull;
             const int n = __popcll(mine);
             const int p = __popcll(mine & (me - 1ull));
             int h = (n - 1) >> 1;                       // -1 for a lane without a candidate
@@ -547,8 +553,18 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             }
             YH_STAMP(4);
             // kept lanes per class -> first output row of each class
-            int* cbase = sseg;
-            cbase[lane] = wave_excl_scan(lane < nc_tab ? __popcll(keys[lane] & kept) : 0);
+            int* cbase = small ? sseg : reinterpret_cast<int*>(keys);
+            if (small) {
+                cbase[lane] = wave_excl_scan(lane < nc_tab ? __popcll(cmask[lane] & kept) : 0);
+            } else {
+                // two classes per lane
+                const int c0 = 2 * lane;
+                const int n0 = c0 < nc_tab ? __popcll(cmask[c0] & kept) : 0;
+                const int n1 = c0 + 1 < nc_tab ? __popcll(cmask[c0 + 1] & kept) : 0;
+                const int base = wave_excl_scan(n0 + n1);
+                cbase[c0] = base;
+                cbase[c0 + 1] = base + n0;
+            }
             group_sync<NT>();
             const bool iskept = (kept >> lane) & 1ull;
             const int pos = iskept ? cbase[ccl[0]] + __popcll(higher & kept) : 0;
