@@ -19,7 +19,7 @@ def b2b(fn, iters=300):
     b.record(); torch.cuda.synchronize()
     return 1e3 * a.elapsed_time(b) / iters
 out = []
-for S, Bx, C, mode in ((7, 2, 20, 1), (8, 2, 20, 1), (7, 2, 24, 1), (10, 1, 20, 0), (6, 3, 80, 1), (7, 2, 80, 0), (8, 1, 128, 1)):
+for S, Bx, C, mode in ((7, 2, 20, 1), (8, 2, 20, 1), (7, 2, 24, 1), (10, 1, 20, 0), (6, 3, 80, 1), (7, 2, 80, 0), (8, 1, 128, 1), (7, 2, 24, 0), (7, 2, 80, 1)):
     pred = synth.make_pred(B, S, Bx, C, seed=3).to(dev)
     dets = torch.empty(B, S * S * Bx, 6, device=dev); cnt = torch.empty(B, dtype=torch.int32, device=dev)
     for conf in (0.5, 0.0):
