@@ -259,6 +259,7 @@ def test_fused_decode_nms(dev, S, Bx, C, batch, mode, ct, it):
     (9, 1, 3, MODE_REFERENCE),   # 81 slots, a candidate per cell
     (6, 3, 20, MODE_DENSE),      # 108 slots, three predictors of a cell in one class
     (5, 3, 7, MODE_DENSE),       # 75 slots
+    (7, 2, 80, MODE_DENSE),      # a compile-time shape with more than 64 classes: ranked, logits in registers
 ])
 @pytest.mark.parametrize("ct,it", [(0.0, 0.5), (0.3, 0.05), (0.5, 0.7)])
 def test_two_candidates_per_lane(dev, S, Bx, C, mode, ct, it):

@@ -224,7 +224,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
     if constexpr (kHead) {
         constexpr bool kStatic = BX_CT > 0 && C_CT > 0;
         // all channels of a cell in registers only while that stays cheap
-        constexpr bool kStaticCell = kStatic && (5 * BX_CT + C_CT <= 48);
+        constexpr bool kStaticCell = kStatic && (5 * BX_CT + C_CT <= 96);
         const int nb = kStatic ? BX_CT : a.nb;
         const int nc = kStatic ? C_CT : a.nc;
         const long long D = 5 * nb + nc;

@@ -165,6 +165,7 @@ int launch_nms(const yh::NmsArgs& a, hipStream_t st) {
         if (a.cell_major) return launch_nms_shape<0, 0, 0, 0, true>(a, st);
         if (a.S == 7 && a.nb == 2 && a.nc == 20) return launch_nms_shape<0, 7, 2, 20>(a, st);
         if (a.S == 14 && a.nb == 5 && a.nc == 80) return launch_nms_shape<0, 14, 5, 80>(a, st);
+        if (a.S == 7 && a.nb == 2 && a.nc == 80) return launch_nms_shape<0, 7, 2, 80>(a, st);
     }
     if constexpr (SRC == 2) {
         if (a.S == 7 && a.nb == 2 && a.nc == 20) return launch_nms_shape<2, 7, 2, 20>(a, st);
