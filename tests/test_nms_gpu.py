@@ -253,13 +253,15 @@ def test_fused_decode_nms(dev, S, Bx, C, batch, mode, ct, it):
 
 @pytest.mark.parametrize("S,Bx,C,mode", [
     (7, 2, 20, MODE_DENSE),      # the headline shape with a candidate per predictor (98 slots)
-    (8, 2, 64, MODE_DENSE),      # all 128 slots, the largest class table of the path without a sort
-    (8, 2, 65, MODE_DENSE),      # one class more: the ranked path
+    (8, 2, 64, MODE_DENSE),      # all 128 slots, the largest class table inside the key array
+    (8, 2, 65, MODE_DENSE),      # one class more: the second half's mask words move to the histogram arrays
+    (8, 2, 128, MODE_DENSE),     # the largest class table without a sort
+    (8, 2, 129, MODE_DENSE),     # one class more: the ranked path
     (8, 2, 1, MODE_DENSE),       # one class of up to 128 members: the masks' second word, long kill chains
     (9, 1, 3, MODE_REFERENCE),   # 81 slots, a candidate per cell
     (6, 3, 20, MODE_DENSE),      # 108 slots, three predictors of a cell in one class
     (5, 3, 7, MODE_DENSE),       # 75 slots
-    (7, 2, 80, MODE_DENSE),      # a compile-time shape with more than 64 classes: ranked, logits in registers
+    (7, 2, 80, MODE_DENSE),      # a compile-time shape with more than 64 classes, logits in registers
 ])
 @pytest.mark.parametrize("ct,it", [(0.0, 0.5), (0.3, 0.05), (0.5, 0.7)])
 def test_two_candidates_per_lane(dev, S, Bx, C, mode, ct, it):

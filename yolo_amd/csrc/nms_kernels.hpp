@@ -591,10 +591,17 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
     // The same without a sort for two candidates per lane (65 to 128 slots, e.g. a
     // candidate per predictor at S=7, Bx=2): slot s = e*64 + lane, every lane mask is
     // 128 bits in two words (word s >> 6, bit s & 63), the class table holds two words
-    // per class and the kill / precedence tables two words per slot.
+    // per class (up to 128 classes) and the kill / precedence tables two words per slot.
     if constexpr (kWave && ITEMS == 2 && kHead) {
         const int nc_tab = C_CT > 0 ? C_CT : a.nc;
-        if (nc_tab <= 64) {
+        if (nc_tab <= 128) {
+            // class -> slot-mask table, a word per class for each half of the slots: both in
+            // the key array for up to 64 classes, else the second half's words in the
+            // (adjacent) histogram and bucket-start arrays, 2 x 4 bytes per class
+            const bool small = nc_tab <= 64;
+            unsigned long long* cm0 = keys;
+            unsigned long long* cm1 =
+                small ? keys + 64 : reinterpret_cast<unsigned long long*>(region + a.off_hist);
             unsigned long long* killt = reinterpret_cast<unsigned long long*>(region + a.off_kill);
             unsigned long long* hight = killt + 256;
             float* sscore = reinterpret_cast<float*>(smeta);
@@ -609,18 +616,22 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                 sbox[s] = make_float4(cbox[e].l, cbox[e].t, cbox[e].r, cbox[e].b);
                 sscore[s] = cscore[e];
             }
+            if (!small) {
+                if (lane < nc_tab) cm1[lane] = 0ull;
+                if (lane + 64 < nc_tab) cm1[lane + 64] = 0ull;
+            }
             group_sync<NT>();
 #pragma unroll
             for (int e = 0; e < 2; ++e)
-                if (cvalid[e]) atomicOr(&keys[2 * ccl[e] + e], me);
+                if (cvalid[e]) atomicOr(e == 0 ? &cm0[ccl[e]] : &cm1[ccl[e]], me);
             group_sync<NT>();
             int h[2];
             unsigned long long rlo[2], rhi[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int s = e * 64 + lane;
-                const unsigned long long m0 = cvalid[e] ? keys[2 * ccl[e]] : 0ull;
-                const unsigned long long m1 = cvalid[e] ? keys[2 * ccl[e] + 1] : 0ull;
+                const unsigned long long m0 = cvalid[e] ? cm0[ccl[e]] : 0ull;
+                const unsigned long long m1 = cvalid[e] ? cm1[ccl[e]] : 0ull;
                 const int n = __popcll(m0) + __popcll(m1);
                 const int p = e == 0 ? __popcll(m0 & (me - 1ull)) : __popcll(m0) + __popcll(m1 & (me - 1ull));
                 h[e] = (n - 1) >> 1;                    // -1 for a slot without a candidate
@@ -684,8 +695,18 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             YH_STAMP(4);
             // kept slots per class -> first output row of each class
             int* cbase = sseg;
-            cbase[lane] = wave_excl_scan(
-                lane < nc_tab ? __popcll(keys[2 * lane] & kept[0]) + __popcll(keys[2 * lane + 1] & kept[1]) : 0);
+            if (small) {
+                cbase[lane] = wave_excl_scan(
+                    lane < nc_tab ? __popcll(cm0[lane] & kept[0]) + __popcll(cm1[lane] & kept[1]) : 0);
+            } else {
+                // two classes per lane
+                const int c0 = 2 * lane;
+                const int n0 = c0 < nc_tab ? __popcll(cm0[c0] & kept[0]) + __popcll(cm1[c0] & kept[1]) : 0;
+                const int n1 = c0 + 1 < nc_tab ? __popcll(cm0[c0 + 1] & kept[0]) + __popcll(cm1[c0 + 1] & kept[1]) : 0;
+                const int base = wave_excl_scan(n0 + n1);
+                cbase[c0] = base;
+                cbase[c0 + 1] = base + n0;
+            }
             group_sync<NT>();
             const int total = __popcll(kept[0]) + __popcll(kept[1]);
             const int nout = a.nout;
