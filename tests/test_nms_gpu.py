@@ -64,6 +64,10 @@ def test_decode_candidates_match_oracle(dev, mode):
     (5, 1, 3, 0.0, 0.5),
     (4, 64, 1, 0.0, 0.3),       # a single class: the longest possible segments
     (4, 128, 2, 0.0, 0.4),
+    (6, 64, 64, 0.0, 0.4),      # classes 0..63: the largest table for candidates handed over in memory
+    (6, 64, 65, 0.3, 0.4),      # a class of 64 or more among the valid ones: the ranked path
+    (6, 100, 64, 0.0, 0.4),
+    (6, 100, 70, 0.2, 0.4),
     (3, 200, 5, 0.2, 0.5),      # one workgroup per image
     (3, 500, 80, 0.001, 0.5),
     (2, 980, 80, 0.001, 0.5),   # the stress shape S=14, B=5, C=80

@@ -492,8 +492,12 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
     // is kept", reached in as many ballot rounds as the longest chain.  The output
     // row is the number of kept lanes of lower classes (per-class counts from the
     // mask table, prefix-summed across lanes) plus the kept lanes in `higher`.
-    if constexpr (kWave && ITEMS == 1 && kHead) {
-        const int nc_tab = C_CT > 0 ? C_CT : a.nc;
+    if constexpr (kWave && ITEMS == 1) {
+        // candidates handed over in memory carry any class up to 32,767: the table in the
+        // key array serves them when every valid one is below 64
+        int nc_tab;
+        if constexpr (kHead) nc_tab = C_CT > 0 ? C_CT : a.nc;
+        else nc_tab = __ballot(cvalid[0] && ccl[0] >= 64) ? 129 : 64;
         if (nc_tab <= 128) {
             // the class -> lane-mask table: the key array for up to 64 classes, else the
             // (adjacent) histogram and bucket-start arrays, 2 x 4 bytes per class
@@ -592,8 +596,10 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
     // candidate per predictor at S=7, Bx=2): slot s = e*64 + lane, every lane mask is
     // 128 bits in two words (word s >> 6, bit s & 63), the class table holds two words
     // per class (up to 128 classes) and the kill / precedence tables two words per slot.
-    if constexpr (kWave && ITEMS == 2 && kHead) {
-        const int nc_tab = C_CT > 0 ? C_CT : a.nc;
+    if constexpr (kWave && ITEMS == 2) {
+        int nc_tab;
+        if constexpr (kHead) nc_tab = C_CT > 0 ? C_CT : a.nc;
+        else nc_tab = __ballot((cvalid[0] && ccl[0] >= 64) || (cvalid[1] && ccl[1] >= 64)) ? 129 : 64;
         if (nc_tab <= 128) {
             // class -> slot-mask table, a word per class for each half of the slots: both in
             // the key array for up to 64 classes, else the second half's words in the
