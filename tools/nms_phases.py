@@ -13,11 +13,12 @@ nblk = (B + 3) // 4
 stamps = torch.zeros(nblk, 16, dtype=torch.int64, device=dev)
 cols = [(0, "entry"), (2, "logits in, candidates decoded"), (3, "class table, pairs"), (4, "kept set"), (15, "rows stored (issued)")]
 K = int(os.environ.get("KB_B2B", "6"))
+MODE = int(os.environ.get("KB_MODE", "0")); CONF = float(os.environ.get("KB_CONF", "0.5"))   # KB_MODE=1: a candidate per predictor
 for label, nsets in (("resident", 1), ("rotating", int(os.environ.get("KB_SETS", "18")))):
     sets = [(base.to(dev).clone(), torch.empty(B, 98, 6, device=dev), torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(nsets)]
     def run(i):
         p, d, c = sets[i % nsets]
-        _lib.check(lib.yh_decode_nms(p.data_ptr(), d.data_ptr(), c.data_ptr(), None, 0, 0.5, 0.5, B, 7, 2, 20, 448, st))
+        _lib.check(lib.yh_decode_nms(p.data_ptr(), d.data_ptr(), c.data_ptr(), None, MODE, CONF, 0.5, B, 7, 2, 20, 448, st))
     for i in range(3 * nsets): run(i)
     torch.cuda.synchronize()
     os.environ["YH_NMS_STAMPS"] = str(stamps.data_ptr())
