@@ -101,7 +101,9 @@ int yh_loss_fwd_bwd(const float* pred, const float* gt_xywh, const float* gt_cls
  * workgroup) go to an array of YH_STATIC_SCRATCH_BYTES that is part of the
  * library image on every GPU the library runs on, for the life of the process;
  * its device address is looked up once per device, on the first call made with
- * that device current.  Same kernels and same bits as yh_loss_fwd_bwd.
+ * that device current (two host-side runtime queries: make that first call outside
+ * graph capture; every later call only enqueues kernels and may be captured).
+ * Same kernels and same bits as yh_loss_fwd_bwd.
  * Limit: yh_workspace_bytes(YH_OP_LOSS, batch, S, Bx, C) <= YH_STATIC_SCRATCH_BYTES
  * (batch <= 65,536 at S = 7; batch <= 16,384 for S >= 12), else YH_ERR_SCRATCH.
  * All calls on one GPU share that GPU's array: calls that overlap there (two
@@ -250,7 +252,8 @@ int yh_box_area(const float* ltrb, float* out, int64_t n, void* stream);
  * confidences by lower index (torch.argsort leaves ties unspecified).
  *   pred (P, 6) rows l,t,r,b,conf,class (the rows yh_decode_nms writes);
  *   gt (G, 5) rows l,t,r,b,class; P, G <= YH_MAP_MAX_ROWS (a whole dataset's
- *   detections in one call, as eval.get_map takes them).  A NaN confidence ranks last.
+ *   detections in one call, as eval.get_map takes them).  A NaN confidence ranks first
+ *   (torch.argsort(descending=True) counts NaN as the largest value, eval.py:121).
  *   ap_out (n_classes) float64, map_out (1) float64 (eval.py:142, :149).
  *   workspace: yh_map_workspace_bytes(P, G) bytes, 256-byte aligned: sort keys and
  *   the temporary storage of the device radix sort.  The call queries the device

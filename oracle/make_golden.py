@@ -217,6 +217,17 @@ def main():
     pr_b = torch.cat([pb, torch.rand(300, 1, generator=gen), pc[:, None]], dim=1)
     cases["b"] = (pr_b, gt_b, 20, 4.0)          # 8 * IoU >= 4.0  <=>  IoU >= 0.5
     cases["c"] = (pr_b[:7], gt_b[:3], 20, 2.0)
+    # case d: NaN confidences.  torch.argsort(descending=True) (eval.py:121) treats a NaN as
+    # larger than every number, so such a row is ranked FIRST; row 77 sits on its ground
+    # truth with its class, so where it ranks changes every precision after it.  (One NaN
+    # only: the order of equal keys, NaNs among themselves included, is not specified by
+    # torch.argsort.)
+    pr_d = pr_b.clone()
+    for r in (77,):
+        pr_d[r, :4] = gt_box[src[r]]
+        pr_d[r, 5] = gt_b[src[r], 4]
+        pr_d[r, 4] = float("nan")
+    cases["d"] = (pr_d, gt_b, 20, 4.0)
     g8 = {}
     for k, (pr, gt_, ncls, thr) in cases.items():
         g8[f"pred_{k}"] = pr.numpy()

@@ -456,8 +456,11 @@ def get_ap(pred, gt, cls_idx, iou_thresh, tp=None):
     if tp is None:
         tp = true_positive_flags(pred, gt, iou_thresh)
     is_true = tp & (pred[:, 5].numpy() == cls_idx)
-    # ties in confidence: the lower index first (torch.argsort leaves them unspecified)
-    order = np.lexsort((np.arange(pred.shape[0]), -pred[:, 4].numpy().astype(np.float64)))
+    # torch.argsort(descending=True) (eval.py:121) counts a NaN as larger than every number:
+    # NaN confidences come first.  Ties (and NaNs among themselves): the lower index first
+    # (torch.argsort leaves them unspecified)
+    conf = pred[:, 4].numpy().astype(np.float64)
+    order = np.lexsort((np.arange(pred.shape[0]), np.where(np.isnan(conf), -np.inf, -conf)))
     accum_tp = np.cumsum(is_true[order])
     with np.errstate(divide="ignore", invalid="ignore"):
         accum_prec = accum_tp / np.arange(1, pred.shape[0] + 1)

@@ -553,10 +553,12 @@ def test_large_blocks_leave_through_a_rolling_window(dev):
 
 @pytest.mark.parametrize("S,Bx,C", [(7, 2, 20), (7, 3, 20), (13, 5, 20)])
 def test_gradient_buffer_not_16_byte_aligned(dev, S, Bx, C):
-    """The kernels that collect a workgroup's gradients in LDS store them in 16-byte
-    units; a gradient buffer that is only 4-byte aligned (legal by the header) takes
-    the kernel that stores directly and must give the same result.  For the run-time
-    shapes the two differ in the store path only: the same bits."""
+    """The kernels that collect a workgroup's gradients in one LDS tile need a 16-byte
+    aligned gradient buffer; one that is only 4-byte aligned (legal by the header) takes
+    the rolling-window kernel at these shapes, which finds the 16-byte grid from the
+    block's address (a few 4-byte stores up to it, 16-byte stores from there) and must
+    give the same result.  For the run-time shapes the two differ in the store path
+    only: the same bits."""
     from yolo_amd import _lib
     lib = _lib.load()
     batch = 37

@@ -9,7 +9,7 @@ from oracle import ref_cpu
 
 def cases(golden):
     g = golden("g8_map.npz")
-    for k in "abc":
+    for k in "abcd":       # d: NaN confidences (ranked first, as torch.argsort does)
         yield (k, g[f"pred_{k}"], g[f"gt_{k}"], int(g[f"ncls_{k}"]), float(g[f"thr_{k}"]),
                float(g[f"map_{k}"]), g[f"ap_{k}"])
 
@@ -67,7 +67,7 @@ def test_gpu_map_edge_cases_and_pipeline(dev):
                                 torch.randint(0, 20, (P, 1), generator=gen).float())], dim=1)
     pl[10, 4] = pl[20, 4]                                        # a confidence tie
     assert box_ops.get_map(pl.to(dev), gtl.to(dev), 20, 4.0).item() == ref_cpu.get_map(pl, gtl, 20, 4.0)
-    # a NaN confidence ranks last (after every number, NaNs among themselves by row)
+    # a NaN confidence ranks first (before every number, NaNs among themselves by row)
     pn = pl.clone()
     pn[5, 4] = float("nan")
     pn[77, 4] = float("nan")
@@ -135,10 +135,10 @@ def test_gpu_map_small_calls(dev):
         ap, m = box_ops._map(pl.to(dev), gtl.to(dev), ncls, thr)
         np.testing.assert_array_equal(ap.cpu().numpy(), want_ap)
         assert m.item() == want_map, (P, G, ncls)
-    # the same rows through the general path: one more prediction that changes nothing
-    # it is ranked last (confidence NaN) and is no true positive
+    # the same rows through the general path: one more prediction that changes nothing --
+    # its confidence is the lowest and it is no true positive
     pl, gtl = _random_problem(1024, 200, 5, seed=11)
-    extra = torch.tensor([[0., 0., 1., 1., float("nan"), 0.]])
+    extra = torch.tensor([[0., 0., 1., 1., -1.0, 0.]])
     a1, m1 = box_ops._map(pl.to(dev), gtl.to(dev), 5, 1.0)
     a2, m2 = box_ops._map(torch.cat([pl, extra]).to(dev), gtl.to(dev), 5, 1.0)
     assert torch.equal(a1, a2) and m1.item() == m2.item() and m1.item() > 0.01

@@ -869,7 +869,10 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_fwd_bwd_roll_kernel(
             ov[u] = og[q];
         }
     }
-    const int pad = (int)(gbase & 3);
+    // position of the block's first float on the 16-byte grid of the ADDRESSES: the buffer
+    // itself may be only 4-byte aligned (this kernel also serves such buffers), and every
+    // 16-byte store below must land on that grid
+    const int pad = (int)((reinterpret_cast<uintptr_t>(gout) >> 2) & 3);
     const int head = n < ((4 - pad) & 3) ? n : ((4 - pad) & 3);   // floats up to the 16-byte grid
     const int body = ((n - head) >> 2) << 2;                      // floats that leave as float4
     // one window [c0, c0 + len) of the block: zero, drop the entries in, store

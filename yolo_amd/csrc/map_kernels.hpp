@@ -105,8 +105,9 @@ __global__ __launch_bounds__(256) void map_tp_key_kernel(
     }
     if (live) {
         tpcls[p] = tp ? ci : -1;
-        // descending sort key; -0 counts as +0 and a NaN confidence ranks last
-        keys[p] = conf != conf ? 0u : float_to_ordered(conf + 0.0f);
+        // descending sort key; -0 counts as +0 and a NaN confidence ranks first, above +inf,
+        // as torch.argsort(descending=True) ranks it (eval.py:121)
+        keys[p] = conf != conf ? 0xFFFFFFFFu : float_to_ordered(conf + 0.0f);
         idx[p] = (unsigned int)p;
     }
 }
@@ -272,9 +273,10 @@ __global__ __launch_bounds__(MAP_SMALL_P) void map_small_kernel(
             }
         }
     }
-    // [63:32] confidence (-0 counts as +0, NaN ranks last), [31:21] inverted row, [20:0] payload;
-    // rows beyond P carry zeros above an inverted row that is lower than any real one
-    const unsigned int ckey = !live || conf != conf ? 0u : float_to_ordered(conf + 0.0f);
+    // [63:32] confidence (-0 counts as +0, a NaN ranks first as in torch.argsort), [31:21]
+    // inverted row, [20:0] payload; rows beyond P carry zeros above an inverted row that is
+    // lower than any real one
+    const unsigned int ckey = !live ? 0u : (conf != conf ? 0xFFFFFFFFu : float_to_ordered(conf + 0.0f));
     const unsigned int payload = tp ? (unsigned int)(ci + 1) : 0u;
     unsigned long long v = ((unsigned long long)ckey << 32) |
                            ((unsigned long long)((unsigned int)(NT - 1 - t) & 0x7FFu) << 21) | payload;

@@ -512,7 +512,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             const bool valid = cvalid[0];
             const float myscore = cscore[0];
             cmask[lane] = 0ull;
-            if (!small) cmask[lane + 64] = 0ull;
+            if (!small && lane + 64 < nc_tab) cmask[lane + 64] = 0ull;   // the table has nc_tab words
             killt[lane] = 0ull;
             hight[lane] = 0ull;
             sbox[lane] = make_float4(cbox[0].l, cbox[0].t, cbox[0].r, cbox[0].b);
