@@ -361,6 +361,18 @@ int yh_decode_nms(const float* pred, float* dets, int32_t* keep_count, int32_t* 
                   int C, int img_size, void* stream);
 
 /*
+ * yh_decode_nms with the row count of `dets` chosen by the caller: dets is
+ * (batch, rows, 6) and keep_idx (batch, rows), rows >= the candidates of the mode
+ * (S*S in YH_MODE_REFERENCE -- model.py:384-390 keeps one box per cell, so no image
+ * can have more detections -- S*S*Bx in YH_MODE_DENSE), else YH_ERR_ARG.  Same keep
+ * rule, order and bits in the rows both calls write; with rows = S*S the reference
+ * mode writes half the bytes yh_decode_nms does at Bx = 2.
+ */
+int yh_decode_nms_rows(const float* pred, float* dets, int32_t* keep_count, int32_t* keep_idx,
+                       int mode, float conf_thresh, float iou_thresh, int rows, int64_t batch, int S,
+                       int Bx, int C, int img_size, void* stream);
+
+/*
  * The same NMS over caller-supplied candidates (N per image, any order; the
  * flat index is the position in the input).  cand_present may be NULL (all
  * present).  Classes must be in [0, 32767].  Any class values give the same

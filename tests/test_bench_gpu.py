@@ -13,12 +13,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(args, extra_env=None, timeout=300):
+def run_bench(args, extra_env=None, timeout=300, drop=()):
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     env.pop("LOCAL_RANK", None)
     env.update(extra_env or {})
+    for name in drop:
+        env.pop(name, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True,
                          text=True, timeout=timeout, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
@@ -41,7 +43,7 @@ def test_two_ranks_self_launched_on_config_3(dev):
 
 def test_one_gpu_line_has_the_contract_keys(dev):
     line = run_bench(["--steps", "20", "--warmup", "4", "--kernel-iters", "40", "--no-stress",
-                      "--cpu-seconds", "1", "--prewarm-seconds", "0.05"])
+                      "--cpu-seconds", "2", "--prewarm-seconds", "0.05"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
@@ -50,5 +52,15 @@ def test_one_gpu_line_has_the_contract_keys(dev):
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / roof["kernel_us"] / 1e3) < 1e-6 * roof["achieved"]
     assert roof["regime"].startswith("buffers rotate")
+    # the headline value is the HBM-proper figure: the timed region rotates through buffer sets
+    assert line["config"]["regime"].startswith("buffers rotate") and line["value_hbm_proper"] == line["value"]
+    assert line["cache_resident"]["images_per_s"] > 0
+    assert roof["copy_ceiling"]["gbs"] > 3000 and roof["copy_ceiling"]["read_only_gbs"] > 3000
+    assert roof["decode_nms"]["rows_written_per_image"] == 49
+    rows = line["configs"]["dp_strong_n1"]["rows"]
+    assert [r["images_on_this_gpu"] for r in rows] == [65536, 32768, 16384, 8192]
+    assert all(r["step_us"] > 0 for r in rows)
+    cb = line["cpu_baseline"]["detail"]["batch4096"]
+    assert all(v["timed_passes"] == 20 and v["warmup_passes"] == 3 for v in cb.values())
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
     assert line["config"]["workload"].startswith("YOLOv1 head S=7,B=2,C=20 batch 4096")

@@ -388,3 +388,29 @@ def test_detections_list_and_empty_batch(dev):
     assert all(x.shape[1] == 6 for x in lst)
     d0, c0 = head.postprocess(torch.zeros(0, 30, 7, 7, device=dev))
     assert d0.shape == (0, 98, 6) and c0.numel() == 0
+
+
+@pytest.mark.parametrize("shape", [(7, 2, 20), (6, 3, 80), (14, 2, 20), (14, 5, 80)])
+def test_row_count_chosen_by_the_caller(dev, shape):
+    """yh_decode_nms_rows: reference mode keeps one box per cell (model.py:384-390), so S*S
+    rows per image hold every detection; the rows, counts and indices equal those of
+    yh_decode_nms, only the zero tail is shorter."""
+    from yolo_amd import _lib
+    S, Bx, C = shape
+    head = YOLOv1Head(img_size=32 * S, n_cells=S, n_bboxes=Bx, n_classes=C)
+    pred = synth.make_pred(9, S, Bx, C, seed=21).to(dev)
+    for mode, conf in ((MODE_REFERENCE, 0.5), (MODE_REFERENCE, 0.0), (MODE_DENSE, 0.3)):
+        full = head.postprocess(pred, conf, 0.5, mode, return_idx=True)
+        nslot = S * S if mode == MODE_REFERENCE else S * S * Bx
+        for rows in (nslot, nslot + 3):
+            dets, count, kidx = head.postprocess(pred, conf, 0.5, mode, return_idx=True, rows=rows)
+            assert dets.shape == (9, rows, 6) and kidx.shape == (9, rows)
+            n = min(rows, full[0].shape[1])
+            assert torch.equal(count, full[1])
+            assert torch.equal(dets[:, :n].view(torch.int32), full[0][:, :n].view(torch.int32))
+            assert torch.equal(kidx[:, :n], full[2][:, :n])
+            assert (dets[:, n:] == 0).all() and (kidx[:, n:] == -1).all()
+            assert int(count.max()) <= nslot
+        with pytest.raises(_lib.YoloHeadError) as e:
+            head.postprocess(pred, conf, 0.5, mode, rows=nslot - 1)
+        assert e.value.rc == _lib.YH_ERR_ARG

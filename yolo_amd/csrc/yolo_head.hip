@@ -722,7 +722,7 @@ namespace {
 int decode_nms_launch(const float* pred, const float* bias, float* dets, int32_t* keep_count,
                       int32_t* keep_idx, int mode, float conf_thresh, float iou_thresh,
                       int64_t batch, int S, int Bx, int C, int img_size, bool with_bias,
-                      void* stream, bool nhwc = false) {
+                      void* stream, bool nhwc = false, int nout = 0) {
     if (const int rc = check_shape(batch, S, Bx, C, img_size)) return rc;
     if (mode != YH_MODE_REFERENCE && mode != YH_MODE_DENSE) return YH_ERR_ARG;
     if (isnan(conf_thresh) || isnan(iou_thresh)) return YH_ERR_ARG;
@@ -743,7 +743,10 @@ int decode_nms_launch(const float* pred, const float* bias, float* dets, int32_t
     a.S = S; a.nb = Bx; a.nc = C; a.mode = mode;
     a.cell_major = nhwc ? 1 : 0;
     a.nslot = mode == YH_MODE_REFERENCE ? S * S : S * S * Bx;
-    a.nout = S * S * Bx;
+    // rows of dets per image: S*S*Bx unless the caller sized the tensor itself (at least one
+    // row per candidate of the mode)
+    if (nout != 0 && (nout < a.nslot || nout > YH_MAX_CANDIDATES)) return YH_ERR_ARG;
+    a.nout = nout != 0 ? nout : S * S * Bx;
     a.cellf = (float)(img_size / S);
     a.imgf = (float)img_size;
     a.conf_thr = conf_thresh;
@@ -764,6 +767,14 @@ int yh_decode_nms(const float* pred, float* dets, int32_t* keep_count, int32_t* 
                   int C, int img_size, void* stream) {
     return decode_nms_launch(pred, nullptr, dets, keep_count, keep_idx, mode, conf_thresh,
                              iou_thresh, batch, S, Bx, C, img_size, false, stream);
+}
+
+int yh_decode_nms_rows(const float* pred, float* dets, int32_t* keep_count, int32_t* keep_idx,
+                       int mode, float conf_thresh, float iou_thresh, int rows, int64_t batch, int S,
+                       int Bx, int C, int img_size, void* stream) {
+    if (rows < 1) return YH_ERR_ARG;
+    return decode_nms_launch(pred, nullptr, dets, keep_count, keep_idx, mode, conf_thresh,
+                             iou_thresh, batch, S, Bx, C, img_size, false, stream, false, rows);
 }
 
 int yh_decode_nms_nhwc(const float* pred, float* dets, int32_t* keep_count, int32_t* keep_idx,

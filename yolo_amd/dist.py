@@ -38,13 +38,22 @@ class LossAllReducer:
     one (steps, 4) tensor of global sums (divide by the global batch for the
     value get_loss reports, model.py:317)."""
 
-    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, always: bool = False):
         self.group = group
+        # always: issue the collective even in a group of one rank (a rehearsal of the
+        # multi-rank path on one GPU); needs an initialised process group
+        self.always = bool(always)
         self._pending: List[Tuple[object, torch.Tensor]] = []
 
     @property
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    @property
+    def _collective(self) -> bool:
+        if self.world_size > 1:
+            return True
+        return self.always and dist.is_available() and dist.is_initialized()
 
     def flush(self, ring: torch.Tensor, n: int) -> None:
         if n <= 0:
@@ -53,7 +62,7 @@ class LossAllReducer:
             raise ValueError(f"{n} rows requested from a ring of {ring.shape[0]}")
         rows = ring[:n].clone()        # the ring is free for the next steps
         work = None
-        if self.world_size > 1:
+        if self._collective:
             if rows.is_cuda and dist.get_backend(self.group) == "gloo":
                 # gloo moves host memory: stage through the CPU (a rehearsal path; the
                 # GPU backend is "nccl" = RCCL and reduces the device buffer in place)
@@ -71,7 +80,7 @@ class LossAllReducer:
         if rows.shape[0] == 0:
             return
         work = None
-        if self.world_size > 1:
+        if self._collective:
             if rows.is_cuda and dist.get_backend(self.group) == "gloo":
                 host = rows.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)

@@ -626,11 +626,15 @@ class YOLOv1Head(nn.Module):
         return ltrb, score, cls, present.view(torch.bool)
 
     def postprocess(self, out, conf_thresh=0.5, iou_thresh=0.5, mode=_lib.YH_MODE_REFERENCE,
-                    return_idx=False, bias: Optional[torch.Tensor] = None):
+                    return_idx=False, bias: Optional[torch.Tensor] = None,
+                    rows: Optional[int] = None):
         """Decode + confidence threshold + per-class NMS in one kernel.
 
         With ``bias`` (S*S*D floats), ``out`` is the last layer's product before its
         bias (model.py:133-135) and the bias is added as the kernel reads it.
+        With ``rows`` the detection tensor has that many rows per image instead of
+        S*S*Bx (at least the candidates of the mode: S*S in reference mode, which keeps
+        one box per cell, model.py:384-390); channel-major ``out`` without a bias only.
 
         Returns dets (B, S*S*Bx, 6) with the kept rows ``l, t, r, b, conf, class``
         first (the row layout eval.py:89-91 consumes; class ascending, then
@@ -643,9 +647,16 @@ class YOLOv1Head(nn.Module):
         if nhwc and (bias is not None or nn_ > _lib.YH_MAX_CANDIDATES):
             raise ValueError("out: a channels-last head tensor is read in place only without a bias and "
                              f"up to {_lib.YH_MAX_CANDIDATES} candidates per image; pass out.contiguous()")
-        dets = torch.empty(bsz, nn_, 6, dtype=torch.float32, device=dev)
+        if rows is not None:
+            if nhwc or bias is not None or nn_ > _lib.YH_MAX_CANDIDATES:
+                raise ValueError("rows: only for a channel-major head tensor without a bias and up to "
+                                 f"{_lib.YH_MAX_CANDIDATES} candidates per image")
+            nrows = int(rows)
+        else:
+            nrows = nn_
+        dets = torch.empty(bsz, nrows, 6, dtype=torch.float32, device=dev)
         count = torch.empty(bsz, dtype=torch.int32, device=dev)
-        kidx = torch.empty(bsz, nn_, dtype=torch.int32, device=dev) if return_idx else None
+        kidx = torch.empty(bsz, nrows, dtype=torch.int32, device=dev) if return_idx else None
         tail = (dets.data_ptr(), count.data_ptr(), _ptr(kidx), int(mode), float(conf_thresh),
                 float(iou_thresh), bsz, self.n_cells, self.n_bboxes, self.n_classes, self.img_size)
         lib = _lib.load()
@@ -660,6 +671,8 @@ class YOLOv1Head(nn.Module):
                                                 ws.numel(), _stream(dev)))
             elif nhwc:
                 _lib.check(lib.yh_decode_nms_nhwc(out.data_ptr(), *tail, _stream(dev)))
+            elif rows is not None:
+                _lib.check(lib.yh_decode_nms_rows(out.data_ptr(), *tail[:6], nrows, *tail[6:], _stream(dev)))
             elif bias is None:
                 _lib.check(lib.yh_decode_nms(out.data_ptr(), *tail, _stream(dev)))
             else:
