@@ -292,7 +292,7 @@ class Kernels:
             b["pred"].data_ptr(), b["gx"].data_ptr(), b["gc"].data_ptr(), b["om"].data_ptr(),
             b["grad"].data_ptr(), b["dets"].data_ptr(), b["cnt"].data_ptr(), None, None,
             log.ring.data_ptr(), log.capacity, log.cursor.data_ptr(), self.wsp.data_ptr(),
-            self.wsp.numel(), self.phase, conf, iou, b["dets"].shape[1], self.batch, s, bx, c, img,
+            self.wsp.numel(), self.phase, 0, conf, iou, b["dets"].shape[1], self.batch, s, bx, c, img,
             5.0, 0.5, self.inv_gb, stream.cuda_stream))
 
 
@@ -380,11 +380,12 @@ def rotation_sets(args, batch):
 
 
 def time_step_graph(torch, dev, K, sets, klog, fused, serial=False, reps=8):
-    """The whole step as the timed region runs it (one graph, 2 * len(sets) steps, at least
-    8), HIP-event timed over `reps` replays.  Returns microseconds per step."""
+    """The whole step as the timed region runs it (one graph of `n` steps: a multiple of the
+    number of buffer sets, at least 64 steps so that the graph's start-up and join weigh
+    little), HIP-event timed over `reps` replays.  Returns microseconds per step."""
     s1 = torch.cuda.Stream(dev)
     s2 = s1 if (serial or fused) else torch.cuda.Stream(dev)
-    n = max(8, 2 * len(sets))
+    n = len(sets) * max(2, -(-64 // len(sets)))
 
     def enqueue():
         if fused:
@@ -594,6 +595,7 @@ def main():
             f"{'fused kernel' if fused else 'two kernels'}, {len(sets)} buffer sets)")
         t_pre = time.perf_counter()
         while time.perf_counter() - t_pre < args.prewarm_seconds:
+            cursor[0] = 0                        # the very graph the timed region starts with
             run_chunk(chunks_of(args.steps)[0])
             torch.cuda.synchronize()
             log.reset()

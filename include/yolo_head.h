@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define YH_VERSION 100 /* 0.1.0 */
+#define YH_VERSION 101 /* 0.1.1 */
 
 #define YH_OK 0
 #define YH_ERR_NULL (-1)        /* a required pointer is NULL */
@@ -371,6 +371,38 @@ int yh_decode_nms(const float* pred, float* dets, int32_t* keep_count, int32_t* 
 int yh_decode_nms_rows(const float* pred, float* dets, int32_t* keep_count, int32_t* keep_idx,
                        int mode, float conf_thresh, float iou_thresh, int rows, int64_t batch, int S,
                        int Bx, int C, int img_size, void* stream);
+
+/*
+ * One call for both halves of a step on the same head tensor: yh_loss_fwd_bwd and
+ * yh_decode_nms_rows, as a validation pass needs them together (the loss of
+ * train.py:100-110 / model.py:296-317 and the detections of model.py:379-394 from one
+ * forward pass).  At S = 7, Bx = 2, C = 20 in YH_MODE_REFERENCE (gt_cls and grad_pred
+ * 16-byte aligned) ONE kernel reads the head tensor once for both; every other case
+ * enqueues the two launches one after the other.  All outputs -- grad_pred, loss_terms,
+ * dets, keep_count, keep_idx -- are bit for bit those of the two separate calls.
+ * rows: rows of dets / keep_idx per image (0: S*S*Bx), as in yh_decode_nms_rows.
+ * workspace: yh_workspace_bytes(YH_OP_LOSS, ...) bytes, 16-byte aligned.
+ *
+ * yh_head_step_pipelined: the same with the loss sums logged one call late, exactly as
+ * yh_loss_fwd_bwd_pipelined does (its contract on phase, workspace --
+ * yh_workspace_bytes(YH_OP_LOSS_PIPELINED, ...), cleared once -- and
+ * yh_loss_pipelined_flush apply unchanged; calls of the two pipelined entry points may
+ * alternate on one workspace): one launch per step.
+ */
+int yh_head_step(const float* pred, const float* gt_xywh, const float* gt_cls,
+                 const uint8_t* obj_mask, float* grad_pred, float* loss_terms, float* dets,
+                 int32_t* keep_count, int32_t* keep_idx, void* workspace, size_t workspace_bytes,
+                 int mode, float conf_thresh, float iou_thresh, int rows, int64_t batch, int S, int Bx,
+                 int C, int img_size, float lambda_coord, float lambda_noobj, float inv_global_batch,
+                 void* stream);
+int yh_head_step_pipelined(const float* pred, const float* gt_xywh, const float* gt_cls,
+                           const uint8_t* obj_mask, float* grad_pred, float* dets,
+                           int32_t* keep_count, int32_t* keep_idx, float* loss_terms_prev,
+                           float* log_ring, int log_capacity, int32_t* log_cursor, void* workspace,
+                           size_t workspace_bytes, int phase, int mode, float conf_thresh,
+                           float iou_thresh, int rows, int64_t batch, int S, int Bx, int C,
+                           int img_size, float lambda_coord, float lambda_noobj,
+                           float inv_global_batch, void* stream);
 
 /*
  * The same NMS over caller-supplied candidates (N per image, any order; the

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_strerror():
     lib = _lib.load()
-    assert lib.yh_version() == 100
+    assert lib.yh_version() == 101
     assert _lib.strerror(0) == "ok"
     for rc in range(-7, 0):
         assert _lib.strerror(rc).startswith("yolo_head:")

@@ -103,6 +103,13 @@ SIGNATURES = {
                               c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "yh_decode_nms_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
                                    c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "yh_head_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_float, c_float, c_int,
+                             c_int64, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p]),
+    "yh_head_step_pipelined": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                       c_size_t, c_int, c_int, c_float, c_float, c_int, c_int64, c_int,
+                                       c_int, c_int, c_int, c_float, c_float, c_float, c_void_p]),
     "yh_nms_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "yh_decode_nms_ws": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                  c_float, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_size_t,

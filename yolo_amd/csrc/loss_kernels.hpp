@@ -914,6 +914,78 @@ constexpr int loss_tile_floats() {
     return loss_ipb_for(S * S) * (5 * BX + C) * S * S + 4;
 }
 
+// Pass 2 of the compile-time-shape loss, by all threads of the workgroup after the barrier
+// behind pass 1.  `olist` holds the listed cells (item = image-in-workgroup * S*S + cell)
+// per wavefront, 64 entries each and in ascending item order, `wcount` their number per
+// wavefront; the j0-th listed cell of the workgroup is worked on by thread j0 (box and
+// confidence work) and by thread LOSS_THREADS/2 + j0 (class work): two wavefronts share what
+// would be one long path.  The cell's logits wait in the tile slots its gradients then take
+// (`tile` = the tile's first float of the workgroup's block).  `gt(w, j, tcell, gx, gc)` sets
+// the addresses of the cell's ground-truth box and class row, given the wavefront whose list
+// holds it, its position there and its cell index in the batch.
+template <int S, int BX, int C, class GT>
+__device__ __forceinline__ void loss_pass2(const int* olist, const int* wcount, float* tile,
+                                           long long img0, const GT& gt, float cellf, float imgf,
+                                           float lc, float ln, float inv_gb, float& acc_coord,
+                                           float& acc_conf, float& acc_cls) {
+    constexpr int D = 5 * BX + C;
+    constexpr int S2 = S * S;
+    int cnt[LOSS_THREADS / 64];
+    int total_obj = 0;
+#pragma unroll
+    for (int q = 0; q < LOSS_THREADS / 64; ++q) { cnt[q] = wcount[q]; total_obj += cnt[q]; }
+    constexpr int HALF = LOSS_THREADS / 2;
+    const bool cls_role = (int)threadIdx.x >= HALF;
+    for (int j0 = (int)threadIdx.x - (cls_role ? HALF : 0); j0 < total_obj; j0 += HALF) {
+        int j = j0;
+        int src = 0;
+#pragma unroll
+        for (int q = 0; q < LOSS_THREADS / 64 - 1; ++q)
+            if (src == q && j >= cnt[q]) { j -= cnt[q]; src = q + 1; }
+        const int item = olist[src * 64 + j];
+        const int gi = item / S2;
+        const int cell = item - gi * S2;
+        const long long img = img0 + gi;
+        const long long tcell = img * S2 + cell;
+        float* gl = tile + gi * (D * S2) + cell;
+        float v[D];
+#pragma unroll
+        for (int ch = 0; ch < D; ++ch) v[ch] = gl[ch * S2];
+        auto logit = [&](int ch) -> float { return v[ch]; };
+        const float *gx, *gc;
+        gt(src, j, tcell, gx, gc);
+        if (cls_role)
+            loss_obj_cell<C, 2>(logit, gl, gx, gc, cell, S, S2, BX, C, cellf, imgf, lc, ln, inv_gb,
+                                acc_coord, acc_conf, acc_cls);
+        else
+            loss_obj_cell<C, 1>(logit, gl, gx, gc, cell, S, S2, BX, C, cellf, imgf, lc, ln, inv_gb,
+                                acc_coord, acc_conf, acc_cls);
+    }
+}
+
+// The workgroup's gradient tile (`sgrad`, its block starting `pad` floats in) leaves for
+// grad[gbase ...] in 16-byte non-temporal stores, whole cache lines per wavefront
+// instruction; the few floats before and after the 16-byte grid go one by one.
+template <int S, int BX, int C>
+__device__ __forceinline__ void loss_tile_store(const float* sgrad, int pad, float* __restrict__ grad,
+                                                long long gbase, long long img0, long long batch) {
+    constexpr int D = 5 * BX + C;
+    constexpr int S2 = S * S;
+    constexpr int IPB = loss_ipb_for(S2);
+    const long long left = batch - img0;
+    const int n = (int)(left < IPB ? left : IPB) * (D * S2);   // floats of this block
+    float* gout = grad + gbase;
+    const int head = (4 - pad) & 3;                             // floats up to the 16-byte grid
+    if ((int)threadIdx.x < head && (int)threadIdx.x < n)
+        gout[threadIdx.x] = sgrad[pad + threadIdx.x];
+    const int n4 = n > head ? (n - head) >> 2 : 0;
+    const float4* s4 = reinterpret_cast<const float4*>(sgrad + pad + head);
+    float4* g4 = reinterpret_cast<float4*>(gout + head);
+    for (int i = threadIdx.x; i < n4; i += LOSS_THREADS) store_stream(g4 + i, s4[i]);
+    const int done = head + 4 * n4;
+    if ((int)threadIdx.x < n - done) gout[done + threadIdx.x] = sgrad[pad + done + threadIdx.x];
+}
+
 // The work of workgroup `bid` of a grid of `nblocks` (with PIPE, workgroup 0 logs
 // the previous call and the others are this call's rows 0, 1, ...); `sgrad` is an
 // LDS tile of loss_tile_floats() floats, 16-byte aligned.
@@ -1008,57 +1080,16 @@ __device__ __forceinline__ void loss_block(
     if (lane == 0) wcount[wave] = __popcll(omask);
     __syncthreads();
     YH_LSTAMP(2);
-    {
-        int cnt[LOSS_THREADS / 64];
-        int total_obj = 0;
-#pragma unroll
-        for (int q = 0; q < LOSS_THREADS / 64; ++q) { cnt[q] = wcount[q]; total_obj += cnt[q]; }
-        // the first half of the workgroup does the box and confidence work of the
-        // listed cells, the second half their class work: two wavefronts share what
-        // would be one long path
-        constexpr int HALF = LOSS_THREADS / 2;
-        const bool cls_role = (int)threadIdx.x >= HALF;
-        for (int j0 = (int)threadIdx.x - (cls_role ? HALF : 0); j0 < total_obj; j0 += HALF) {
-            int j = j0;
-            int src = 0;
-#pragma unroll
-            for (int q = 0; q < LOSS_THREADS / 64 - 1; ++q)
-                if (src == q && j >= cnt[q]) { j -= cnt[q]; src = q + 1; }
-            const int item = olist[src * 64 + j];
-            const int gi = item / S2;
-            const int cell = item - gi * S2;
-            const long long img = img0 + gi;
-            const long long tcell = img * S2 + cell;
-            float* gl = sgrad + pad + gi * (D * S2) + cell;
-            float v[D];
-#pragma unroll
-            for (int ch = 0; ch < D; ++ch) v[ch] = gl[ch * S2];
-            auto logit = [&](int ch) -> float { return v[ch]; };
-            if (cls_role)
-                loss_obj_cell<C, 2>(logit, gl, gt_xywh + tcell * 4, gt_cls + tcell * C, cell, S, S2,
-                                    BX, C, cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf, acc_cls);
-            else
-                loss_obj_cell<C, 1>(logit, gl, gt_xywh + tcell * 4, gt_cls + tcell * C, cell, S, S2,
-                                    BX, C, cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf, acc_cls);
-        }
-    }
+    loss_pass2<S, BX, C>(olist, wcount, sgrad + pad, img0,
+                         [&](int, int, long long tcell, const float*& gx, const float*& gc) {
+                             gx = gt_xywh + tcell * 4;
+                             gc = gt_cls + tcell * C;
+                         },
+                         cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf, acc_cls);
     YH_LSTAMP(3);
     loss_block_reduce(acc_coord, acc_conf, acc_cls, partials, bid);   // has a barrier after the LDS writes
     YH_LSTAMP(4);
-    {
-        const long long left = batch - img0;
-        const int n = (int)(left < IPB ? left : IPB) * (D * S2);   // floats of this block
-        float* gout = grad + gbase;
-        const int head = (4 - pad) & 3;                             // floats up to the 16-byte grid
-        if ((int)threadIdx.x < head && (int)threadIdx.x < n)
-            gout[threadIdx.x] = sgrad[pad + threadIdx.x];
-        const int n4 = n > head ? (n - head) >> 2 : 0;
-        const float4* s4 = reinterpret_cast<const float4*>(sgrad + pad + head);
-        float4* g4 = reinterpret_cast<float4*>(gout + head);
-        for (int i = threadIdx.x; i < n4; i += LOSS_THREADS) store_stream(g4 + i, s4[i]);
-        const int done = head + 4 * n4;
-        if ((int)threadIdx.x < n - done) gout[done + threadIdx.x] = sgrad[pad + done + threadIdx.x];
-    }
+    loss_tile_store<S, BX, C>(sgrad, pad, grad, gbase, img0, batch);
     YH_LSTAMP(5);
 }
 

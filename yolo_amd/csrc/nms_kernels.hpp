@@ -147,6 +147,30 @@ __device__ __forceinline__ Box cell_box(const L& logit, int k, int cell, int S, 
                            cell, S, cellf, imgf);
 }
 
+// The candidate of a cell in reference mode (model.py:384-394) from the cell's 5 BX + C
+// logits held in registers: the predictor with the higher confidence, its box, its
+// confidence and the cell's class.
+template <int BX, int C>
+__device__ __forceinline__ void cell_candidate_from_registers(float (&v)[5 * BX + C], int cell, int S,
+                                                              float cellf, float imgf, Box& box,
+                                                              float& conf, int& cls, int& k) {
+    auto logit = [&](int ch) -> float { return v[ch]; };
+    k = cell_best_conf(logit, BX, conf);
+    // The box logits of EVERY predictor are wanted in registers here.  Without this the
+    // compiler turns "select among loaded values" into "load from a selected address", and
+    // the four loads of the chosen box become a second, dependent trip to memory behind the
+    // confidence compare.
+#pragma unroll
+    for (int q = 0; q < BX; ++q)
+        asm volatile("" : "+v"(v[5 * q]), "+v"(v[5 * q + 1]), "+v"(v[5 * q + 2]), "+v"(v[5 * q + 3]));
+    float lx = v[0], ly = v[1], lw = v[2], lh = v[3];
+#pragma unroll
+    for (int q = 1; q < BX; ++q)
+        if (k == q) { lx = v[5 * q]; ly = v[5 * q + 1]; lw = v[5 * q + 2]; lh = v[5 * q + 3]; }
+    box = box_from_logits(lx, ly, lw, lh, cell, S, cellf, imgf);
+    cls = cell_class(logit, 5 * BX, C);
+}
+
 template <int NT>
 __device__ __forceinline__ void group_sync() {
     if constexpr (NT == 64) {
@@ -157,6 +181,121 @@ __device__ __forceinline__ void group_sync() {
     } else {
         __syncthreads();
     }
+}
+
+// LDS tables of the sort-free NMS of one wavefront (one candidate per lane)
+struct WaveNmsTables {
+    unsigned long long* cmask;   // class -> mask of the lanes that hold a valid candidate of it (nc_tab words)
+    unsigned long long* killt;   // per lane: lanes ahead of it in output order whose IoU with it exceeds the threshold
+    unsigned long long* hight;   // per lane: lanes of its class ahead of it in output order
+    float4* sbox;                // per lane: its box
+    float* sscore;               // per lane: its score
+    int* cbase;                  // per class: first output row (nc_tab ints, at least 64)
+};
+
+// Per-class greedy NMS of one image by ONE wavefront, one candidate per lane, at most 128
+// classes (nc_tab), no sort.  The lanes of a class find each other through the class ->
+// lane-mask table (one 64-bit OR per lane).  Every pair of a class is then looked at once,
+// the pairs of a class of n spread evenly over its members: a member takes the (n-1)/2
+// members that follow it cyclically in lane order (one more for the first half of an even
+// class), so the loop runs about half as long as the largest class.  For a pair, the member
+// that comes later in the output order (lower score, higher index on equal scores) gets the
+// other one's bit in its `higher` word and, when their IoU exceeds the threshold, in its
+// `killers` word (LDS ORs).  Greedy NMS is the fixed point "kept iff no killer is kept",
+// reached in as many ballot rounds as the longest chain.  The output row is the number of
+// kept lanes of lower classes (per-class counts from the mask table, prefix-summed across
+// lanes) plus the kept lanes in `higher`.  Rows go to `dets` (nout rows of 6 floats, kept
+// rows first, zero rows after them), flat indices to `kidx` (may be null), the count to
+// *count.  All 64 lanes of the wavefront must call; `stamp(i)` marks phase boundaries in
+// probe builds.
+template <class STAMP>
+__device__ __forceinline__ void nms_wave_one_per_lane(const WaveNmsTables& tb, int nc_tab, const Box& cbox,
+                                                      float myscore, int ccl, int cidx, bool valid,
+                                                      float iou_thr, float* dets, int32_t* kd,
+                                                      int32_t* count, int nout, const STAMP& stamp) {
+    constexpr int NT = 64;
+    const int lane = threadIdx.x & 63;
+    const bool small = nc_tab <= 64;
+    unsigned long long* cmask = tb.cmask;
+    unsigned long long* killt = tb.killt;
+    unsigned long long* hight = tb.hight;
+    float4* sbox = tb.sbox;
+    float* sscore = tb.sscore;
+    const unsigned long long me = 1ull << lane;
+    cmask[lane] = 0ull;
+    if (!small && lane + 64 < nc_tab) cmask[lane + 64] = 0ull;   // the table has nc_tab words
+    killt[lane] = 0ull;
+    hight[lane] = 0ull;
+    sbox[lane] = make_float4(cbox.l, cbox.t, cbox.r, cbox.b);
+    sscore[lane] = myscore;
+    group_sync<NT>();
+    if (valid) atomicOr(&cmask[ccl], me);
+    group_sync<NT>();
+    const unsigned long long mine = valid ? cmask[ccl] : 0ull;
+    const int n = __popcll(mine);
+    const int p = __popcll(mine & (me - 1ull));
+    int h = (n - 1) >> 1;                       // -1 for a lane without a candidate
+    if (n > 0 && (n & 1) == 0 && p < (n >> 1)) ++h;
+    // bit k of `rot` is lane (lane + 1 + k) & 63: the members after this one, cyclically
+    const int sh = (lane + 1) & 63;
+    unsigned long long rot = sh ? (mine >> sh) | (mine << (64 - sh)) : mine;
+    const IouBand band = make_iou_band(iou_thr);
+    while (__ballot(h > 0)) {
+        if (h > 0) {
+            --h;
+            const int j = (lane + __ffsll((long long)rot)) & 63;    // ffs = k + 1
+            rot &= rot - 1ull;
+            const float sj = sscore[j];
+            const float4 b = sbox[j];
+            const bool j_first = sj > myscore || (sj == myscore && j < lane);
+            const int later = j_first ? lane : j;
+            const unsigned long long first_bit = 1ull << (j_first ? j : lane);
+            atomicOr(&hight[later], first_bit);
+            if (iou_above_band({b.x, b.y, b.z, b.w}, cbox, band)) atomicOr(&killt[later], first_bit);
+        }
+    }
+    group_sync<NT>();
+    stamp(3);
+    const unsigned long long killers = killt[lane], higher = hight[lane];
+    unsigned long long undec = __ballot(valid), kept = 0ull;
+    while (undec) {
+        const bool und = (undec >> lane) & 1ull;
+        const bool die = und && (killers & kept) != 0ull;
+        const bool keep = und && !die && (killers & undec) == 0ull;
+        const unsigned long long km = __ballot(keep);
+        kept |= km;
+        undec &= ~(km | __ballot(die));
+    }
+    stamp(4);
+    // kept lanes per class -> first output row of each class
+    int* cbase = tb.cbase;
+    if (small) {
+        cbase[lane] = wave_excl_scan(lane < nc_tab ? __popcll(cmask[lane] & kept) : 0);
+    } else {
+        // two classes per lane
+        const int c0 = 2 * lane;
+        const int n0 = c0 < nc_tab ? __popcll(cmask[c0] & kept) : 0;
+        const int n1 = c0 + 1 < nc_tab ? __popcll(cmask[c0 + 1] & kept) : 0;
+        const int base = wave_excl_scan(n0 + n1);
+        cbase[c0] = base;
+        cbase[c0 + 1] = base + n0;
+    }
+    group_sync<NT>();
+    const bool iskept = (kept >> lane) & 1ull;
+    const int pos = iskept ? cbase[ccl] + __popcll(higher & kept) : 0;
+    const int total = __popcll(kept);
+    float2* dst2 = reinterpret_cast<float2*>(dets);
+    if (iskept) {
+        float2* row = dst2 + pos * 3;
+        store_stream(row + 0, make_float2(cbox.l, cbox.t));
+        store_stream(row + 1, make_float2(cbox.r, cbox.b));
+        store_stream(row + 2, make_float2(myscore, (float)ccl));
+        if (kd) kd[pos] = cidx;
+    }
+    for (int i = total * 3 + lane; i < nout * 3; i += NT) store_stream(dst2 + i, make_float2(0.0f, 0.0f));
+    if (kd)
+        for (int i = total + lane; i < nout; i += NT) kd[i] = -1;
+    if (lane == 0) *count = total;
 }
 
 // SRC 0: candidates decoded from the head tensor (S_CT, BX_CT, C_CT > 0: grid
@@ -295,23 +434,8 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
 #pragma unroll
                             for (int ch = 0; ch < 5 * BX_CT + C_CT; ++ch) v[ch] += bq[ch * S2];
                         }
-                        auto logit = [&](int ch) -> float { return v[ch]; };
-                        k = cell_best_conf(logit, BX_CT, cb);
-                        // The box logits of EVERY predictor are wanted in registers here.
-                        // Without this the compiler turns "select among loaded values" into
-                        // "load from a selected address", and the four loads of the chosen
-                        // box become a second, dependent trip to memory behind the
-                        // confidence compare.
-#pragma unroll
-                        for (int q = 0; q < BX_CT; ++q)
-                            asm volatile("" : "+v"(v[5 * q]), "+v"(v[5 * q + 1]), "+v"(v[5 * q + 2]),
-                                              "+v"(v[5 * q + 3]));
-                        float lx = v[0], ly = v[1], lw = v[2], lh = v[3];
-#pragma unroll
-                        for (int q = 1; q < BX_CT; ++q)
-                            if (k == q) { lx = v[5 * q]; ly = v[5 * q + 1]; lw = v[5 * q + 2]; lh = v[5 * q + 3]; }
-                        cbox[e] = box_from_logits(lx, ly, lw, lh, cell, S, a.cellf, a.imgf);
-                        ccl[e] = cell_class(logit, 5 * BX_CT, C_CT);
+                        cell_candidate_from_registers<BX_CT, C_CT>(v, cell, S, a.cellf, a.imgf, cbox[e], cb,
+                                                                   ccl[e], k);
                     } else {
                         const MemLogitsT<kBias> logit{p, kBias ? a.bias + cell : nullptr, chs};
                         k = cell_best_conf(logit, nb, cb);
@@ -479,19 +603,8 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
 #ifdef YH_PHASE_PROBE
     if (a.dbg_stop == 1) { if (cvalid[0] && cscore[0] == 12345.f) a.keep_count[img] = ccl[0] + (int)cbox[0].l; return; }
 #endif
-    // One wavefront per image, one candidate per lane, at most 128 classes: no sort.
-    // The lanes of a class find each other through a class -> lane
-    // mask table in LDS (one 64-bit OR per lane).  Every pair of a class is then
-    // looked at once, the pairs of a class of n spread evenly over its members: a
-    // member takes the (n-1)/2 members that follow it cyclically in lane order (one
-    // more for the first half of an even class), so the loop runs about half as
-    // long as the largest class.  For a pair, the member that comes later in the
-    // output order (lower score, higher index on equal scores) gets the other one's
-    // bit in its `higher` word and, when their IoU exceeds the threshold, in its
-    // `killers` word (LDS ORs).  Greedy NMS is the fixed point "kept iff no killer
-    // is kept", reached in as many ballot rounds as the longest chain.  The output
-    // row is the number of kept lanes of lower classes (per-class counts from the
-    // mask table, prefix-summed across lanes) plus the kept lanes in `higher`.
+    // One wavefront per image, one candidate per lane, at most 128 classes: no sort
+    // (nms_wave_one_per_lane).
     if constexpr (kWave && ITEMS == 1) {
         // candidates handed over in memory carry any class up to 32,767: the table in the
         // key array serves them when every valid one is below 64
@@ -502,91 +615,18 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             // the class -> lane-mask table: the key array for up to 64 classes, else the
             // (adjacent) histogram and bucket-start arrays, 2 x 4 bytes per class
             const bool small = nc_tab <= 64;
-            unsigned long long* cmask =
-                small ? keys : reinterpret_cast<unsigned long long*>(region + a.off_hist);
-            unsigned long long* killt = reinterpret_cast<unsigned long long*>(region + a.off_kill);
-            unsigned long long* hight = killt + 64;
-            float* sscore = reinterpret_cast<float*>(smeta);
+            WaveNmsTables tb;
+            tb.cmask = small ? keys : reinterpret_cast<unsigned long long*>(region + a.off_hist);
+            tb.killt = reinterpret_cast<unsigned long long*>(region + a.off_kill);
+            tb.hight = tb.killt + 64;
+            tb.sbox = sbox;
+            tb.sscore = reinterpret_cast<float*>(smeta);
+            tb.cbase = small ? sseg : reinterpret_cast<int*>(keys);
             YH_STAMP(2);
-            const unsigned long long me = 1ull << lane;
-            const bool valid = cvalid[0];
-            const float myscore = cscore[0];
-            cmask[lane] = 0ull;
-            if (!small && lane + 64 < nc_tab) cmask[lane + 64] = 0ull;   // the table has nc_tab words
-            killt[lane] = 0ull;
-            hight[lane] = 0ull;
-            sbox[lane] = make_float4(cbox[0].l, cbox[0].t, cbox[0].r, cbox[0].b);
-            sscore[lane] = myscore;
-            group_sync<NT>();
-            if (valid) atomicOr(&cmask[ccl[0]], me);
-            group_sync<NT>();
-            const unsigned long long mine = valid ? cmask[ccl[0]] : 0ull;
-            const int n = __popcll(mine);
-            const int p = __popcll(mine & (me - 1ull));
-            int h = (n - 1) >> 1;                       // -1 for a lane without a candidate
-            if (n > 0 && (n & 1) == 0 && p < (n >> 1)) ++h;
-            // bit k of `rot` is lane (lane + 1 + k) & 63: the members after this one, cyclically
-            const int sh = (lane + 1) & 63;
-            unsigned long long rot = sh ? (mine >> sh) | (mine << (64 - sh)) : mine;
-            const IouBand band = make_iou_band(a.iou_thr);
-            while (__ballot(h > 0)) {
-                if (h > 0) {
-                    --h;
-                    const int j = (lane + __ffsll((long long)rot)) & 63;    // ffs = k + 1
-                    rot &= rot - 1ull;
-                    const float sj = sscore[j];
-                    const float4 b = sbox[j];
-                    const bool j_first = sj > myscore || (sj == myscore && j < lane);
-                    const int later = j_first ? lane : j;
-                    const unsigned long long first_bit = 1ull << (j_first ? j : lane);
-                    atomicOr(&hight[later], first_bit);
-                    if (iou_above_band({b.x, b.y, b.z, b.w}, cbox[0], band)) atomicOr(&killt[later], first_bit);
-                }
-            }
-            group_sync<NT>();
-            YH_STAMP(3);
-            const unsigned long long killers = killt[lane], higher = hight[lane];
-            unsigned long long undec = __ballot(valid), kept = 0ull;
-            while (undec) {
-                const bool und = (undec >> lane) & 1ull;
-                const bool die = und && (killers & kept) != 0ull;
-                const bool keep = und && !die && (killers & undec) == 0ull;
-                const unsigned long long km = __ballot(keep);
-                kept |= km;
-                undec &= ~(km | __ballot(die));
-            }
-            YH_STAMP(4);
-            // kept lanes per class -> first output row of each class
-            int* cbase = small ? sseg : reinterpret_cast<int*>(keys);
-            if (small) {
-                cbase[lane] = wave_excl_scan(lane < nc_tab ? __popcll(cmask[lane] & kept) : 0);
-            } else {
-                // two classes per lane
-                const int c0 = 2 * lane;
-                const int n0 = c0 < nc_tab ? __popcll(cmask[c0] & kept) : 0;
-                const int n1 = c0 + 1 < nc_tab ? __popcll(cmask[c0 + 1] & kept) : 0;
-                const int base = wave_excl_scan(n0 + n1);
-                cbase[c0] = base;
-                cbase[c0 + 1] = base + n0;
-            }
-            group_sync<NT>();
-            const bool iskept = (kept >> lane) & 1ull;
-            const int pos = iskept ? cbase[ccl[0]] + __popcll(higher & kept) : 0;
-            const int total = __popcll(kept);
-            const int nout = a.nout;
-            float2* dst2 = reinterpret_cast<float2*>(a.dets + img * (long long)nout * 6);
-            int32_t* kd = a.keep_idx ? a.keep_idx + img * (long long)nout : nullptr;
-            if (iskept) {
-                float2* row = dst2 + pos * 3;
-                store_stream(row + 0, make_float2(cbox[0].l, cbox[0].t));
-                store_stream(row + 1, make_float2(cbox[0].r, cbox[0].b));
-                store_stream(row + 2, make_float2(cscore[0], (float)ccl[0]));
-                if (kd) kd[pos] = cidx[0];
-            }
-            for (int i = total * 3 + t; i < nout * 3; i += NT) store_stream(dst2 + i, make_float2(0.0f, 0.0f));
-            if (kd)
-                for (int i = total + t; i < nout; i += NT) kd[i] = -1;
-            if (t == 0) a.keep_count[img] = total;
+            nms_wave_one_per_lane(tb, nc_tab, cbox[0], cscore[0], ccl[0], cidx[0], cvalid[0], a.iou_thr,
+                                  a.dets + img * (long long)a.nout * 6,
+                                  a.keep_idx ? a.keep_idx + img * (long long)a.nout : nullptr,
+                                  a.keep_count + img, a.nout, [&](int i) { YH_STAMP(i); (void)i; });
             YH_STAMP(15);
             return;
         }

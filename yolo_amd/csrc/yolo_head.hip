@@ -13,6 +13,7 @@
 #include "decode_kernels.hpp"
 #include "loss_kernels.hpp"
 #include "nms_kernels.hpp"
+#include "step_kernels.hpp"
 #include "target_kernels.hpp"
 #include "box_kernels.hpp"
 
@@ -820,3 +821,106 @@ int yh_nms(const float* cand_ltrb, const float* cand_score, const int32_t* cand_
 }
 
 }  // extern "C"
+
+namespace {
+
+// Both halves of a step on one stream.  The tuned shape in reference mode takes ONE kernel
+// that reads the head tensor once (head_step_kernel); every other case is the loss launch
+// followed by the decode + NMS launch -- the same bits either way.  `pipe` as in loss_launch.
+int head_step_launch(const float* pred, const float* gt_xywh, const float* gt_cls,
+                     const uint8_t* obj_mask, float* grad_pred, float* dets, int32_t* keep_count,
+                     int32_t* keep_idx, float* rows_base, const yh::LossPipe* pipe, int mode,
+                     float conf_thresh, float iou_thresh, int rows, int64_t batch, int S, int Bx, int C,
+                     int img_size, float lambda_coord, float lambda_noobj, float inv_global_batch,
+                     hipStream_t st) {
+    if (mode != YH_MODE_REFERENCE && mode != YH_MODE_DENSE) return YH_ERR_ARG;
+    if (isnan(conf_thresh) || isnan(iou_thresh) || rows < 0) return YH_ERR_ARG;
+    if ((int64_t)S * S * Bx > YH_MAX_CANDIDATES) return YH_ERR_UNSUPPORTED;
+    const int nslot = mode == YH_MODE_REFERENCE ? S * S : S * S * Bx;
+    if (rows != 0 && (rows < nslot || rows > YH_MAX_CANDIDATES)) return YH_ERR_ARG;
+    if (batch > 0 && (!pred || !gt_xywh || !gt_cls || !obj_mask || !grad_pred || !dets || !keep_count))
+        return YH_ERR_NULL;
+    if (!aligned(gt_xywh, 16) || !aligned(pred, 4) || !aligned(grad_pred, 4) || !aligned(gt_cls, 4) ||
+        !aligned(dets, 8) || !aligned(keep_count, 4) || !aligned(keep_idx, 4))
+        return YH_ERR_ALIGN;
+    if (isnan(lambda_coord) || isnan(lambda_noobj) || isnan(inv_global_batch)) return YH_ERR_ARG;
+    const bool one_kernel = S == 7 && Bx == 2 && C == 20 && mode == YH_MODE_REFERENCE &&
+                            aligned(gt_cls, 16) && aligned(grad_pred, 16);
+    if (!one_kernel) {
+        if (const int rc = loss_launch(pred, nullptr, gt_xywh, gt_cls, obj_mask, grad_pred, rows_base,
+                                       batch, S, Bx, C, img_size, lambda_coord, lambda_noobj,
+                                       inv_global_batch, pipe, st))
+            return rc;
+        return decode_nms_launch(pred, nullptr, dets, keep_count, keep_idx, mode, conf_thresh,
+                                 iou_thresh, batch, S, Bx, C, img_size, false, st, false, rows);
+    }
+    const int64_t nrows = loss_blocks(batch, S);
+    if (nrows == 0 && !pipe) return YH_OK;
+    yh::StepArgs a = {};
+    a.pred = pred; a.gt_xywh = gt_xywh; a.gt_cls = gt_cls; a.obj_mask = obj_mask;
+    a.grad = grad_pred; a.partials = rows_base;
+    a.dets = dets; a.keep_count = keep_count; a.keep_idx = keep_idx;
+    a.batch = batch;
+    a.nout = rows != 0 ? rows : S * S * Bx;
+    a.cellf = (float)(img_size / S); a.imgf = (float)img_size;
+    a.lc = lambda_coord; a.ln = lambda_noobj; a.inv_gb = inv_global_batch;
+    a.conf_thr = conf_thresh; a.iou_thr = iou_thresh;
+    if (pipe) a.pipe = *pipe;
+    const dim3 grid((unsigned)(nrows + (pipe ? 1 : 0)));
+    if (pipe)
+        hipLaunchKernelGGL((yh::head_step_kernel<7, 2, 20, true>), grid, dim3(yh::LOSS_THREADS), 0, st, a);
+    else
+        hipLaunchKernelGGL((yh::head_step_kernel<7, 2, 20, false>), grid, dim3(yh::LOSS_THREADS), 0, st, a);
+    return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int yh_head_step(const float* pred, const float* gt_xywh, const float* gt_cls,
+                 const uint8_t* obj_mask, float* grad_pred, float* loss_terms, float* dets,
+                 int32_t* keep_count, int32_t* keep_idx, void* workspace, size_t workspace_bytes,
+                 int mode, float conf_thresh, float iou_thresh, int rows, int64_t batch, int S, int Bx,
+                 int C, int img_size, float lambda_coord, float lambda_noobj, float inv_global_batch,
+                 void* stream) {
+    if (const int rc = check_shape(batch, S, Bx, C, img_size)) return rc;
+    if (!loss_terms) return YH_ERR_NULL;
+    if (!workspace) return YH_ERR_WORKSPACE;
+    if (workspace_bytes < yh_workspace_bytes(YH_OP_LOSS, batch, S, Bx, C)) return YH_ERR_WORKSPACE;
+    if (!aligned(workspace, 16)) return YH_ERR_ALIGN;
+    if (const int rc = head_step_launch(pred, gt_xywh, gt_cls, obj_mask, grad_pred, dets, keep_count,
+                                        keep_idx, (float*)workspace, nullptr, mode, conf_thresh,
+                                        iou_thresh, rows, batch, S, Bx, C, img_size, lambda_coord,
+                                        lambda_noobj, inv_global_batch, (hipStream_t)stream))
+        return rc;
+    return yh_loss_finalize(workspace, workspace_bytes, batch, S, inv_global_batch, loss_terms,
+                            nullptr, 0, nullptr, stream);
+}
+
+int yh_head_step_pipelined(const float* pred, const float* gt_xywh, const float* gt_cls,
+                           const uint8_t* obj_mask, float* grad_pred, float* dets,
+                           int32_t* keep_count, int32_t* keep_idx, float* loss_terms_prev,
+                           float* log_ring, int log_capacity, int32_t* log_cursor, void* workspace,
+                           size_t workspace_bytes, int phase, int mode, float conf_thresh,
+                           float iou_thresh, int rows, int64_t batch, int S, int Bx, int C,
+                           int img_size, float lambda_coord, float lambda_noobj,
+                           float inv_global_batch, void* stream) {
+    if (const int rc = check_shape(batch, S, Bx, C, img_size)) return rc;
+    if (phase != 0 && phase != 1) return YH_ERR_ARG;
+    if (const int rc = check_log(loss_terms_prev, log_ring, log_capacity, log_cursor)) return rc;
+    PipeHalves h;
+    const size_t need = yh_workspace_bytes(YH_OP_LOSS_PIPELINED, batch, S, Bx, C) / 2;
+    if (const int rc = pipe_halves(workspace, workspace_bytes, need, h)) return rc;
+    char* own = h.half[phase];
+    char* prev = h.half[1 - phase];
+    const yh::LossPipe pipe{(int*)own, (int*)prev, (const float*)(prev + 16), loss_terms_prev,
+                            log_ring, (int*)log_cursor, log_capacity};
+    return head_step_launch(pred, gt_xywh, gt_cls, obj_mask, grad_pred, dets, keep_count, keep_idx,
+                            (float*)(own + 16), &pipe, mode, conf_thresh, iou_thresh, rows, batch, S, Bx,
+                            C, img_size, lambda_coord, lambda_noobj, inv_global_batch,
+                            (hipStream_t)stream);
+}
+
+}  // extern "C"
+

@@ -345,6 +345,94 @@ class YOLOv1Head(nn.Module):
         state[1] = phase
         return grad
 
+    def _check_step_args(self, out, gt_norm_xywh, gt_cls_prob, obj_mask, mode, rows):
+        out = self._check_out(out.detach())
+        bsz, n = out.shape[0], self.n_grid
+        _need(gt_norm_xywh, "gt_norm_xywh", torch.float32, (bsz, n, 1, 4))
+        _need(gt_cls_prob, "gt_cls_prob", torch.float32, (bsz, n, 1, self.n_classes))
+        if obj_mask.dtype == torch.bool:
+            obj_mask = obj_mask.view(torch.uint8)
+        _need(obj_mask, "obj_mask", torch.uint8, (bsz, n, 1, 1))
+        for name, t in (("gt_norm_xywh", gt_norm_xywh), ("gt_cls_prob", gt_cls_prob),
+                        ("obj_mask", obj_mask)):
+            if t.device != out.device:
+                raise ValueError(f"{name}: on {t.device}, out is on {out.device}")
+        nn_ = n * self.n_bboxes
+        if nn_ > _lib.YH_MAX_CANDIDATES:
+            raise ValueError(f"head_step: up to {_lib.YH_MAX_CANDIDATES} candidates per image")
+        nrows = nn_ if rows is None else int(rows)
+        return out, obj_mask, bsz, nrows
+
+    def head_step(self, out, gt_norm_xywh, gt_cls_prob, obj_mask, conf_thresh=0.5, iou_thresh=0.5,
+                  mode=_lib.YH_MODE_REFERENCE, global_batch=None, rows: Optional[int] = None,
+                  return_idx=False):
+        """Loss forward + backward AND decode + NMS of the same head tensor in one call (a
+        validation pass wants both from one forward, train.py:100-110): returns
+        ``(terms, grad, dets, count[, keep_idx])``, each the bits ``loss_fwd_bwd`` and
+        ``postprocess(..., rows=rows)`` return.  At S=7, Bx=2, C=20 in reference mode one
+        kernel reads the head tensor once for both."""
+        out, obj_mask, bsz, nrows = self._check_step_args(out, gt_norm_xywh, gt_cls_prob, obj_mask, mode, rows)
+        dev = out.device
+        lib = _lib.load()
+        gb = bsz if global_batch is None else int(global_batch)
+        shape = (bsz, self.n_cells, self.n_bboxes, self.n_classes)
+        ws = self._get_workspace(dev, lib.yh_workspace_bytes(_lib.YH_OP_LOSS, *shape))
+        grad = torch.empty_like(out)
+        terms = torch.empty(5, dtype=torch.float32, device=dev)
+        dets = torch.empty(bsz, nrows, 6, dtype=torch.float32, device=dev)
+        count = torch.empty(bsz, dtype=torch.int32, device=dev)
+        kidx = torch.empty(bsz, nrows, dtype=torch.int32, device=dev) if return_idx else None
+        with _on_device(dev):
+            pending = self._fin_event.pop(dev, None)
+            if pending is not None:
+                torch.cuda.current_stream(dev).wait_event(pending)
+            _lib.check(lib.yh_head_step(
+                out.data_ptr(), gt_norm_xywh.data_ptr(), gt_cls_prob.data_ptr(), obj_mask.data_ptr(),
+                grad.data_ptr(), terms.data_ptr(), dets.data_ptr(), count.data_ptr(), _ptr(kidx),
+                ws.data_ptr(), ws.numel(), int(mode), float(conf_thresh), float(iou_thresh),
+                0 if rows is None else nrows, *shape, self.img_size, self.coord_coeff,
+                self.noobj_coeff, 1.0 / max(gb, 1), _stream(dev)))
+        self.last_loss_terms = terms
+        return (terms, grad, dets, count, kidx) if return_idx else (terms, grad, dets, count)
+
+    def head_step_pipelined(self, out, gt_norm_xywh, gt_cls_prob, obj_mask, log: "LossLog",
+                            conf_thresh=0.5, iou_thresh=0.5, mode=_lib.YH_MODE_REFERENCE,
+                            global_batch=None, rows: Optional[int] = None,
+                            terms_prev: Optional[torch.Tensor] = None):
+        """``head_step`` as ONE launch per step: the loss sums reach ``log`` during the next
+        call (or at ``flush_loss_log``), as with ``loss_step_pipelined``, whose workspace
+        and phase counter it shares.  Returns ``(grad, dets, count)``."""
+        out, obj_mask, bsz, nrows = self._check_step_args(out, gt_norm_xywh, gt_cls_prob, obj_mask, mode, rows)
+        dev = out.device
+        if log.ring.device != dev:
+            raise ValueError(f"loss log on {log.ring.device}, out is on {dev}")
+        if terms_prev is not None:
+            _need(terms_prev, "terms_prev", torch.float32, (5,))
+        lib = _lib.load()
+        gb = bsz if global_batch is None else int(global_batch)
+        shape = (bsz, self.n_cells, self.n_bboxes, self.n_classes)
+        nbytes = lib.yh_workspace_bytes(_lib.YH_OP_LOSS_PIPELINED, *shape)
+        state = self._pipe.get(dev)
+        if state is None or state[0].numel() < nbytes:
+            if state is not None:
+                self.flush_loss_log(log)         # the halves move: log what is pending first
+            state = [torch.zeros(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev), 1]
+            self._pipe[dev] = state
+        ws, phase = state[0], 1 - state[1]
+        grad = torch.empty_like(out)
+        dets = torch.empty(bsz, nrows, 6, dtype=torch.float32, device=dev)
+        count = torch.empty(bsz, dtype=torch.int32, device=dev)
+        with _on_device(dev):
+            _lib.check(lib.yh_head_step_pipelined(
+                out.data_ptr(), gt_norm_xywh.data_ptr(), gt_cls_prob.data_ptr(), obj_mask.data_ptr(),
+                grad.data_ptr(), dets.data_ptr(), count.data_ptr(), None, _ptr(terms_prev),
+                log.ring.data_ptr(), log.capacity, log.cursor.data_ptr(), ws.data_ptr(), ws.numel(),
+                phase, int(mode), float(conf_thresh), float(iou_thresh), 0 if rows is None else nrows,
+                *shape, self.img_size, self.coord_coeff, self.noobj_coeff, 1.0 / max(gb, 1),
+                _stream(dev)))
+        state[1] = phase
+        return grad, dets, count
+
     def flush_loss_log(self, log: "LossLog", terms: Optional[torch.Tensor] = None):
         """Logs the step ``loss_step_pipelined`` still holds back (no-op if none)."""
         state = self._pipe.get(log.ring.device)
