@@ -25,6 +25,11 @@ constexpr int LOSS_THREADS = 256;
 // with one workgroup more than the rest, and the launch waits for those (12.0 -> 11.2 us
 // over rotating buffers; three: 14.0, two: 14.2).
 constexpr int loss_ipb_for(int S2) { return S2 == 49 ? 4 : LOSS_THREADS / S2; }
+// ground-truth slots per wavefront of the compile-time-shape loss kernel (0: pass 2 fetches)
+#ifndef YH_LOSS_GT_SLOTS
+#define YH_LOSS_GT_SLOTS 16
+#endif
+constexpr int LOSS_GT_SLOTS = YH_LOSS_GT_SLOTS;
 
 #ifdef YH_PHASE_PROBE
 // probe builds only: eight time stamps per workgroup (100 MHz counter) of loss_block
@@ -1026,64 +1031,85 @@ __device__ __forceinline__ void loss_block(
     __shared__ int olist[LOSS_THREADS];
     __shared__ int wcount[LOSS_THREADS / 64];
     static_assert(IPB * S2 <= LOSS_THREADS, "one cell per lane");
+    // The ground truth of a listed cell is requested by the lane that owns the cell, together
+    // with the cell's logits (one trip to memory), and waits in LDS for pass 2: per wavefront
+    // LOSS_GT_SLOTS slots of 4 + C floats, in list order; a cell beyond them is fetched by its
+    // pass-2 lanes (a second, dependent trip).
+    constexpr bool kPark = LOSS_GT_SLOTS > 0 && C % 4 == 0;
+    constexpr int GTF = 4 + C;
+    __shared__ __attribute__((aligned(16))) float gtpark[kPark ? (LOSS_THREADS / 64) * LOSS_GT_SLOTS * GTF : 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float acc_coord = 0.f, acc_conf = 0.f, acc_cls = 0.f;
-    bool has_obj = false;
     {
         const int item = threadIdx.x;
         const int gi = item / S2;
         const int cell = item - gi * S2;
         const long long img = img0 + gi;
-        if (item < nitems && img < batch) {
-            const long long tcell = img * S2 + cell;
-            // every cell needs its confidence logits: requested together with the mask
-            float vc[BX];
-            {
-                const float* p = pred + img * (long long)D * S2 + cell;
+        const bool mine = item < nitems && img < batch;
+        const long long tcell = mine ? img * S2 + cell : 0;
+        const float* p = pred + (mine ? img * (long long)D * S2 + cell : 0);
+        // every cell needs its confidence logits: requested together with the mask
+        float vc[BX];
 #pragma unroll
-                for (int k = 0; k < BX; ++k) vc[k] = p[(5 * k + 4) * S2];
+        for (int k = 0; k < BX; ++k) vc[k] = mine ? p[(5 * k + 4) * S2] : 0.0f;
+        const bool has_obj = mine && obj_mask[tcell] != 0;
+        // the cells that hold an object are listed per wavefront, in cell order
+        const unsigned long long omask = __ballot(has_obj);
+        const int opos = __popcll(omask & ((1ull << lane) - 1ull));
+        if (has_obj) olist[wave * 64 + opos] = threadIdx.x;
+        if (lane == 0) wcount[wave] = __popcll(omask);
+        if (has_obj) {
+            // the cell's logits are requested now and wait for pass 2 in the very tile
+            // slots their gradients will take, its ground truth in its slot of the wavefront's
+            // list (one memory round trip less on the path of the two wavefronts that do pass 2)
+            float v[D];
+#pragma unroll
+            for (int ch = 0; ch < D; ++ch) {
+                if (ch < 5 * BX && ch % 5 == 4) v[ch] = vc[ch / 5];
+                else v[ch] = p[ch * S2];
             }
-            has_obj = obj_mask[tcell] != 0;
-            if (has_obj) {
-                // the cell's logits are requested now and wait for pass 2 in the very tile
-                // slots their gradients will take (one memory round trip less on the
-                // path of the two wavefronts that do pass 2)
-                const float* p = pred + img * (long long)D * S2 + cell;
-                float v[D];
+            if constexpr (kPark) {
+                if (opos < LOSS_GT_SLOTS) {
+                    float4 gq[GTF / 4];
+                    gq[0] = *reinterpret_cast<const float4*>(gt_xywh + tcell * 4);
+                    const float4* gc4 = reinterpret_cast<const float4*>(gt_cls + tcell * C);
 #pragma unroll
-                for (int ch = 0; ch < D; ++ch) {
-                    if (ch < 5 * BX && ch % 5 == 4) v[ch] = vc[ch / 5];
-                    else v[ch] = p[ch * S2];
+                    for (int q = 0; q < C / 4; ++q) gq[1 + q] = gc4[q];
+                    float4* slot = reinterpret_cast<float4*>(gtpark) + (wave * LOSS_GT_SLOTS + opos) * (GTF / 4);
+#pragma unroll
+                    for (int q = 0; q < GTF / 4; ++q) slot[q] = gq[q];
                 }
-                if constexpr (BIAS) {
-                    const float* bq = bias + cell;
-#pragma unroll
-                    for (int ch = 0; ch < D; ++ch) v[ch] += bq[ch * S2];
-                }
-                float* gl = sgrad + pad + gi * (D * S2) + cell;
-#pragma unroll
-                for (int ch = 0; ch < D; ++ch) gl[ch * S2] = v[ch];
-            } else {
-                if constexpr (BIAS) {
-#pragma unroll
-                    for (int k = 0; k < BX; ++k) vc[k] += bias[(5 * k + 4) * S2 + cell];
-                }
-                auto logit = [&](int ch) -> float { return vc[ch / 5]; };   // asked for 5k+4 only
-                loss_noobj_cell(logit, sgrad + pad + gi * (D * S2) + cell, S2, BX, C, ln, inv_gb,
-                                acc_conf);
             }
+            if constexpr (BIAS) {
+                const float* bq = bias + cell;
+#pragma unroll
+                for (int ch = 0; ch < D; ++ch) v[ch] += bq[ch * S2];
+            }
+            float* gl = sgrad + pad + gi * (D * S2) + cell;
+#pragma unroll
+            for (int ch = 0; ch < D; ++ch) gl[ch * S2] = v[ch];
+        } else if (mine) {
+            if constexpr (BIAS) {
+#pragma unroll
+                for (int k = 0; k < BX; ++k) vc[k] += bias[(5 * k + 4) * S2 + cell];
+            }
+            auto logit = [&](int ch) -> float { return vc[ch / 5]; };   // asked for 5k+4 only
+            loss_noobj_cell(logit, sgrad + pad + gi * (D * S2) + cell, S2, BX, C, ln, inv_gb,
+                            acc_conf);
         }
     }
     YH_LSTAMP(1);
-    const unsigned long long omask = __ballot(has_obj);
-    if (has_obj) olist[wave * 64 + __popcll(omask & ((1ull << lane) - 1ull))] = threadIdx.x;
-    if (lane == 0) wcount[wave] = __popcll(omask);
     __syncthreads();
     YH_LSTAMP(2);
     loss_pass2<S, BX, C>(olist, wcount, sgrad + pad, img0,
-                         [&](int, int, long long tcell, const float*& gx, const float*& gc) {
-                             gx = gt_xywh + tcell * 4;
-                             gc = gt_cls + tcell * C;
+                         [&](int w, int j, long long tcell, const float*& gx, const float*& gc) {
+                             if (kPark && j < LOSS_GT_SLOTS) {
+                                 gx = gtpark + (w * LOSS_GT_SLOTS + j) * GTF;
+                                 gc = gx + 4;
+                             } else {
+                                 gx = gt_xywh + tcell * 4;
+                                 gc = gt_cls + tcell * C;
+                             }
                          },
                          cellf, imgf, lc, ln, inv_gb, acc_coord, acc_conf, acc_cls);
     YH_LSTAMP(3);

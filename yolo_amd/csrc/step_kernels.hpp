@@ -90,6 +90,7 @@ __global__ __launch_bounds__(LOSS_THREADS, 4) void head_step_kernel(const StepAr
     const bool live = lane < S2 && img < a.batch;    // this lane owns a cell
     const int cell = lane < S2 ? lane : 0;
     const int item = wave * S2 + cell;               // the cell's index in the workgroup's block
+    YH_LSTAMP(0);
 
     // ---- 1. the cell's logits, its mask byte, then its ground truth --------------------
     float v[D];
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(LOSS_THREADS, 4) void head_step_kernel(const StepAr
     if (lane == 0) wcount[wave] = __popcll(omask);
     if (lane < S2) sconf[item] = conf_term;
     if (threadIdx.x >= IPB * S2) sconf[threadIdx.x] = 0.f;   // the lanes beyond the block's items
+    YH_LSTAMP(1);
 
     // ---- 3. NMS of this wavefront's image ------------------------------------------------
     unsigned char* region = wlds[wave];
@@ -159,6 +161,7 @@ __global__ __launch_bounds__(LOSS_THREADS, 4) void head_step_kernel(const StepAr
                               a.keep_count + img, a.nout, [](int) {});
     }
 
+    YH_LSTAMP(2);
     // ---- 4. the ground truth is parked where the NMS tables were; pass 2 ---------------------
     group_sync<64>();                                      // this wavefront's table reads are done
     if (has_obj && opos < GT_SLOTS) {
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(LOSS_THREADS, 4) void head_step_kernel(const StepAr
         for (int q = 0; q < GT_FLOATS / 4; ++q) slot[q] = gq[q];
     }
     __syncthreads();
+    YH_LSTAMP(3);
     float acc_coord = 0.f, acc_cls = 0.f;
     float acc_conf = sconf[threadIdx.x];                   // as if thread i had done item i in pass 1
     loss_pass2<S, BX, C>(olist, wcount, sgrad + pad, img0,
@@ -180,8 +184,11 @@ __global__ __launch_bounds__(LOSS_THREADS, 4) void head_step_kernel(const StepAr
                              }
                          },
                          a.cellf, a.imgf, a.lc, a.ln, a.inv_gb, acc_coord, acc_conf, acc_cls);
+    YH_LSTAMP(4);
     loss_block_reduce(acc_coord, acc_conf, acc_cls, a.partials, bid);   // has a barrier after the LDS writes
+    YH_LSTAMP(5);
     loss_tile_store<S, BX, C>(sgrad, pad, a.grad, gbase, img0, a.batch);
+    YH_LSTAMP(6);
 }
 
 }  // namespace yh
