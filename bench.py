@@ -63,7 +63,7 @@ MALL_BYTES = 256 * 1024 * 1024  # memory-side cache (Infinity Cache)
 S, BX, C, IMG = 7, 2, 20, 448
 CONF_T, IOU_T = 0.5, 0.5
 STRONG_GLOBAL_BATCH = 65536
-KERNEL_SOURCES = ("head_math.hpp", "loss_kernels.hpp", "nms_kernels.hpp", "yolo_head.hip")
+KERNEL_SOURCES = ("head_math.hpp", "loss_kernels.hpp", "nms_kernels.hpp", "step_kernels.hpp", "yolo_head.hip")
 
 
 def loss_bytes_per_image(s=S, bx=BX, c=C):
@@ -787,32 +787,59 @@ def measure_kernels(args, torch, dev, K, sets, log, result, batch, rank, fused):
     def gbs(nbytes, us):
         return nbytes / (us * 1e-6) / 1e9
 
-    main_us = (rot or res)["loss_fwd_bwd_us"]
-    achieved = gbs(algo, main_us)
+    # The dominant kernel of the step as it ran: the one-kernel step when the step is fused
+    # (it is the whole step), else the loss kernel.  Its algorithmic bytes: the per-image
+    # figures of loss_bytes_per_image / nms_bytes_per_image, the head tensor counted once
+    # for the kernel that reads it once.
+    hs_algo = algo + nms_algo - 4 * (5 * BX + C) * S * S * batch
+    src = rot or res
+    if fused and src.get("head_step_us"):
+        main_us, main_algo, main_traffic = src["head_step_us"], hs_algo, step_traffic
+        main_name = "head_step_kernel<%d,%d,%d,true>" % (S, BX, C)
+        main_note = ("loss fwd+bwd and decode+NMS in one launch; algorithmic bytes = head tensor read ONCE + "
+                     "targets read + gradient written + (batch, S*S*Bx, 6) detections + counts; the bytes it "
+                     "moves are fewer still: targets of cells without an object are never read and "
+                     "yh_decode_nms_rows-style S*S rows are written")
+    else:
+        main_us, main_algo, main_traffic = src["loss_fwd_bwd_us"], algo, traffic
+        main_name = "loss_fwd_bwd_kernel<%d,%d,%d,%s,false>" % (S, BX, C, "true" if K.pipelined else "false")
+        main_note = ("the kernel never reads the targets of cells without an object, so the bytes it moves "
+                     "(PMC) are below the algorithmic count")
+    achieved = gbs(main_algo, main_us)
     roof = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-        "achieved_counter_bytes": gbs(traffic, main_us) if traffic else None,
-        "frac_counter_bytes": gbs(traffic, main_us) / HBM_PEAK_GBS if traffic else None,
-        "counter_bytes_note": "the kernel never reads the targets of cells without an object, so the bytes "
-                              "it moves (PMC) are below the algorithmic count; `frac` prices the "
-                              "algorithmic bytes, `frac_counter_bytes` the bytes moved",
-        "kernel": "loss_fwd_bwd_kernel<%d,%d,%d,%s,false>" % (S, BX, C, "true" if K.pipelined else "false"),
+        "frac": achieved / HBM_PEAK_GBS, "traffic": main_traffic, "traffic_source": traffic_note,
+        "achieved_counter_bytes": gbs(main_traffic, main_us) if main_traffic else None,
+        "frac_counter_bytes": gbs(main_traffic, main_us) / HBM_PEAK_GBS if main_traffic else None,
+        "counter_bytes_note": main_note + "; `frac` prices the algorithmic bytes, `frac_counter_bytes` the bytes moved",
+        "kernel": main_name,
         "regime": "buffers rotate past the memory-side cache (HBM proper)" if rot
                   else "one resident buffer set (memory-side cache)",
-        "algorithmic_bytes_per_launch": algo,
+        "algorithmic_bytes_per_launch": main_algo,
         "kernel_us": main_us,
     }
+    if fused and src.get("head_step_us"):
+        roof["two_kernel_algorithmic_bytes"] = algo + nms_algo
+        roof["frac_on_two_kernel_bytes"] = gbs(algo + nms_algo, main_us) / HBM_PEAK_GBS
     if rot:
         rot["loss_fwd_bwd_frac"] = gbs(algo, rot["loss_fwd_bwd_us"]) / HBM_PEAK_GBS
         rot["decode_nms_frac"] = gbs(nms_algo, rot["decode_nms_us"]) / HBM_PEAK_GBS
+        if rot.get("head_step_us"):
+            rot["head_step_frac"] = gbs(hs_algo, rot["head_step_us"]) / HBM_PEAK_GBS
         roof["beyond_memory_side_cache"] = rot
     if res:
         res["loss_fwd_bwd_frac"] = gbs(algo, res["loss_fwd_bwd_us"]) / HBM_PEAK_GBS
         res["decode_nms_frac"] = gbs(nms_algo, res["decode_nms_us"]) / HBM_PEAK_GBS
+        if res.get("head_step_us"):
+            res["head_step_frac"] = gbs(hs_algo, res["head_step_us"]) / HBM_PEAK_GBS
         res["note"] = "cache-assisted: a fraction above what HBM delivers is the memory-side cache, not HBM"
         roof["infinity_cache_resident"] = res
-    nms_us = (rot or res)["decode_nms_us"]
+    loss_us = src["loss_fwd_bwd_us"]
+    roof["loss_fwd_bwd"] = {
+        "kernel": "loss_fwd_bwd_kernel<%d,%d,%d,%s,false>" % (S, BX, C, "true" if K.pipelined else "false"),
+        "algorithmic_bytes_per_launch": algo, "kernel_us": loss_us, "frac": gbs(algo, loss_us) / HBM_PEAK_GBS,
+        "traffic": traffic, "frac_counter_bytes": gbs(traffic, loss_us) / HBM_PEAK_GBS if traffic else None}
+    nms_us = src["decode_nms_us"]
     roof["decode_nms"] = {
         "kernel": "nms_kernel<64,1,0,%d,%d,%d>" % (S, BX, C), "algorithmic_bytes_per_launch": nms_algo,
         "kernel_us": nms_us, "frac": gbs(nms_algo, nms_us) / HBM_PEAK_GBS,
@@ -824,23 +851,12 @@ def measure_kernels(args, torch, dev, K, sets, log, result, batch, rank, fused):
         "note": "`frac` prices the algorithmic bytes of a (batch, S*S*Bx, 6) detection tensor; reference "
                 "mode has at most S*S candidates and yh_decode_nms_rows writes that many rows per "
                 "image, which `frac_rows_written` prices"}
-    if K.has_fused and (rot or res).get("head_step_us"):
-        hs_us = (rot or res)["head_step_us"]
-        hs_algo = algo + nms_algo - 4 * (5 * BX + C) * S * S * batch     # the head tensor counted once
-        roof["head_step"] = {
-            "kernel": "head_step_kernel<%d,%d,%d,true>" % (S, BX, C),
-            "algorithmic_bytes_per_launch": hs_algo, "kernel_us": hs_us,
-            "frac": gbs(hs_algo, hs_us) / HBM_PEAK_GBS,
-            "two_kernel_algorithmic_bytes": algo + nms_algo,
-            "frac_on_two_kernel_bytes": gbs(algo + nms_algo, hs_us) / HBM_PEAK_GBS,
-            "traffic": step_traffic,
-            "frac_counter_bytes": gbs(step_traffic, hs_us) / HBM_PEAK_GBS if step_traffic else None}
     if args.measure == "all":
         cc = copy_ceiling(torch, dev, st)
         roof["copy_ceiling"] = cc
         roof["frac_of_copy_ceiling"] = achieved / cc["gbs"]
-        if traffic:
-            roof["frac_counter_bytes_of_copy_ceiling"] = gbs(traffic, main_us) / cc["gbs"]
+        if main_traffic:
+            roof["frac_counter_bytes_of_copy_ceiling"] = gbs(main_traffic, main_us) / cc["gbs"]
         if roof["frac_of_copy_ceiling"] > 1.0:
             roof["frac_of_copy_ceiling_note"] = ("above 1 because the algorithmic bytes include target rows "
                                                  "the kernel never reads; see frac_counter_bytes_of_copy_ceiling")

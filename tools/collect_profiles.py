@@ -30,8 +30,8 @@ for counter, d in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir)):
     path = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
     for r in csv.DictReader(open(path)):
         n = r["Kernel_Name"]
-        if any(k in n for k in ("loss_fwd", "nms_kernel", "rocclr_copyBuffer")):
-            key = "loss" if "loss_fwd" in n else "nms" if "nms_kernel" in n else "copy"
+        if any(k in n for k in ("loss_fwd", "nms_kernel", "head_step", "rocclr_copyBuffer")):
+            key = "loss" if "loss_fwd" in n else "nms" if "nms_kernel" in n else "step" if "head_step" in n else "copy"
             vals.setdefault((counter, key), []).append(float(r["Counter_Value"]))
             if (key == "copy" and float(r["Counter_Value"]) > 30000) or (key != "copy" and len(vals[(counter, key)]) <= 6):      # the first launches of each, as a sample
                 out.append([counter, r["Dispatch_Id"], n[:70], r["Grid_Size"], r["Workgroup_Size"], r["VGPR_Count"], r["Counter_Value"]])
@@ -39,7 +39,7 @@ med = lambda x: sorted(x)[len(x) // 2]
 with open(f"profiles/{tag}_pmc_hbm_traffic.csv", "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["# rocprofv3 --pmc FETCH_SIZE -- python3 tools/pmc_driver.py  and  rocprofv3 --pmc WRITE_SIZE -- python3 tools/pmc_driver.py (separate passes); Counter_Value in KiB"])
-    w.writerow(["# the two rocclr_copyBuffer dispatches of 64 MiB are the calibration copies (known bytes): FETCH_SIZE reads 1/2 of the bytes, WRITE_SIZE exact; then 34 launches of the loss kernel (pipelined step) and 34 of decode+NMS, batch 4096, over 17 rotating buffer sets (first six of each listed, medians of all below)"])
+    w.writerow(["# the two rocclr_copyBuffer dispatches of 64 MiB are the calibration copies (known bytes): FETCH_SIZE reads 1/2 of the bytes, WRITE_SIZE exact; then 34 launches each of the loss kernel (pipelined step), of decode+NMS (49 rows per image) and of the one-kernel step, batch 4096, over 17 rotating buffer sets (first six of each listed, medians of all below)"])
     w.writerow(["counter", "dispatch", "kernel", "grid", "workgroup", "vgpr", "value_KiB"])
     w.writerows(out)
     for (counter, key), v in sorted(vals.items()):
@@ -47,6 +47,7 @@ with open(f"profiles/{tag}_pmc_hbm_traffic.csv", "w", newline="") as f:
             w.writerow([counter, "median", key, len(v), "", "", f"{med(v):.4f}"])
 fl, wl = med(vals[("FETCH_SIZE", "loss")]), med(vals[("WRITE_SIZE", "loss")])
 fn, wn = med(vals[("FETCH_SIZE", "nms")]), med(vals[("WRITE_SIZE", "nms")])
+fs, wst = med(vals[("FETCH_SIZE", "step")]), med(vals[("WRITE_SIZE", "step")])
 fc = [v for v in vals[("FETCH_SIZE", "copy")] if 30000 < v < 36000]    # the 64 MiB calibration copies
 tj = {
     "batch": 4096, "profile": tag, "sources_sha": bench.kernel_sources_sha(),
@@ -59,6 +60,8 @@ tj = {
     "loss_kernel_hbm_bytes_per_launch": int((2 * fl + wl) * 1024),
     "nms_kernel_fetch_size_kib_raw": fn, "nms_kernel_write_size_kib": wn,
     "nms_kernel_hbm_bytes_per_launch": int((2 * fn + wn) * 1024),
+    "head_step_kernel_fetch_size_kib_raw": fs, "head_step_kernel_write_size_kib": wst,
+    "head_step_kernel_hbm_bytes_per_launch": int((2 * fs + wst) * 1024),
 }
 json.dump(tj, open("profiles/traffic.json", "w"), indent=1)
-print(tj["loss_kernel_hbm_bytes_per_launch"], tj["nms_kernel_hbm_bytes_per_launch"])
+print(tj["loss_kernel_hbm_bytes_per_launch"], tj["nms_kernel_hbm_bytes_per_launch"], tj["head_step_kernel_hbm_bytes_per_launch"])
