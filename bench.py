@@ -325,6 +325,8 @@ def bench_lib():
                                         ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         lib.yhb_stream_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                         ctypes.c_void_p]
+        lib.yhb_stream_rw.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                      ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         _bench_lib = lib
     return _bench_lib
 
@@ -369,6 +371,31 @@ def copy_ceiling(torch, dev, stream):
             "kernel": "libyhbench stream_copy_kernel<2, nt loads, nt stores>, 16,384 workgroups",
             "read_only_gbs": (1 << 30) / (us_read * 1e-6) / 1e9,
             "torch_copy_gbs": 2 * (1 << 30) / (us_torch * 1e-6) / 1e9}
+
+
+def streaming_floor(torch, dev, stream, rbytes, wbytes, iters=200):
+    """Duration of a plain streaming kernel with a given traffic -- rbytes read, wbytes written,
+    16 bytes per lane, non-temporal -- launched back to back over a rotation of buffers that
+    exceeds twice the memory-side cache: what the memory system alone allows a one-launch
+    kernel of that size (ramp and drain included).  Microseconds per launch."""
+    lib = bench_lib()
+    rb, wb = (int(rbytes) + 15) & ~15, (int(wbytes) + 15) & ~15
+    wb = min(wb, rb)
+    nsets = -(-2 * MALL_BYTES // min(rb, max(wb, 1 << 20))) + 1
+    nsets = max(2, min(nsets, 128))
+    src = [torch.empty(rb // 4, device=dev).normal_() for _ in range(nsets)]
+    dst = [torch.empty(max(wb, 16) // 4, device=dev) for _ in range(nsets)]
+    sink = torch.zeros(1, device=dev)
+    st = stream.cuda_stream
+
+    def run(i):
+        rc = lib.yhb_stream_rw(src[i].data_ptr(), rb, dst[i].data_ptr(), wb, sink.data_ptr(), 4096, st)
+        if rc:
+            raise SystemExit(f"yhb_stream_rw failed: {rc}")
+
+    us = time_launches(torch, run, nsets, iters, stream)
+    del src, dst
+    return us
 
 
 def rotation_sets(args, batch):
@@ -857,6 +884,30 @@ def measure_kernels(args, torch, dev, K, sets, log, result, batch, rank, fused):
         roof["frac_of_copy_ceiling"] = achieved / cc["gbs"]
         if main_traffic:
             roof["frac_counter_bytes_of_copy_ceiling"] = gbs(main_traffic, main_us) / cc["gbs"]
+        # what a plain streaming kernel needs for each kernel's traffic, one launch at a time over
+        # rotating buffers: the bytes the PMC counters saw when known, else the algorithmic bytes
+        d4, cells = 4 * (5 * BX + C) * S * S * batch, S * S * batch
+        shapes = {"loss_fwd_bwd": (d4 + cells * (4 * (4 + C) + 1), d4),
+                  "decode_nms": (d4, (24 * K.rows(0) + 4) * batch),
+                  "head_step": (d4 + cells * (4 * (4 + C) + 1), d4 + (24 * K.rows(0) + 4) * batch)}
+        basis = "algorithmic bytes (read, written)"
+        tpath2 = os.path.join(ROOT, "profiles", "traffic.json")
+        if main_traffic and os.path.exists(tpath2):
+            tj = json.load(open(tpath2))
+            for key, name in (("loss_fwd_bwd", "loss_kernel"), ("decode_nms", "nms_kernel"), ("head_step", "head_step_kernel")):
+                if tj.get(name + "_fetch_size_kib_raw"):
+                    shapes[key] = (int(2048 * tj[name + "_fetch_size_kib_raw"]), int(1024 * tj[name + "_write_size_kib"]))
+            basis = "bytes the PMC counters saw (FETCH_SIZE doubled, WRITE_SIZE)"
+        floor = {"basis": basis, "kernel": "libyhbench stream_rw_kernel<2>, 4,096 workgroups, non-temporal, "
+                                           "back to back over rotating buffers"}
+        for key, us_key in (("loss_fwd_bwd", "loss_fwd_bwd_us"), ("decode_nms", "decode_nms_us"), ("head_step", "head_step_us")):
+            if not src.get(us_key):
+                continue
+            rb, wb = shapes[key]
+            fus = streaming_floor(torch, dev, st, rb, wb)
+            floor[key] = {"read_bytes": rb, "written_bytes": wb, "streaming_kernel_us": fus,
+                          "kernel_us": src[us_key], "kernel_over_streaming": src[us_key] / fus}
+        roof["streaming_floor"] = floor
         if roof["frac_of_copy_ceiling"] > 1.0:
             roof["frac_of_copy_ceiling_note"] = ("above 1 because the algorithmic bytes include target rows "
                                                  "the kernel never reads; see frac_counter_bytes_of_copy_ceiling")

@@ -51,7 +51,7 @@ def test_constants_match_header():
 
 def test_workspace_bytes():
     lib = _lib.load()
-    # S=7: five images per 256-thread workgroup, one 16-byte row per workgroup
+    # S=7: four images per 256-thread workgroup, one 16-byte row per workgroup
     assert lib.yh_workspace_bytes(_lib.YH_OP_LOSS, 4096, 7, 2, 20) == (4096 // 4) * 16
     assert lib.yh_workspace_bytes(_lib.YH_OP_LOSS, 0, 7, 2, 20) == 16
     assert lib.yh_workspace_bytes(_lib.YH_OP_LOSS, 16, 14, 5, 80) == 16 * 16

@@ -56,9 +56,102 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const v4f* __restrict_
     if (acc.x + acc.y + acc.z + acc.w == 1.2345e38f) *sink = acc.x;
 }
 
+// reads n_r chunks of 16 bytes and writes the first n_w of them back out (n_w <= n_r): the
+// traffic shape of a kernel that reads more than it writes, as a plain streaming kernel
+template <int UNROLL>
+__global__ __launch_bounds__(256) void stream_rw_kernel(const v4f* __restrict__ src, v4f* __restrict__ dst,
+                                                        float* __restrict__ sink, long long n_r,
+                                                        long long n_w) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (; i + (UNROLL - 1) * stride < n_r; i += UNROLL * stride) {
+        v4f v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (i + u * stride < n_w) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+            else acc += v[u];
+        }
+    }
+    for (; i < n_r; i += stride) {
+        const v4f v = __builtin_nontemporal_load(src + i);
+        if (i < n_w) __builtin_nontemporal_store(v, dst + i);
+        else acc += v;
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 1.2345e38f) *sink = acc.x;   // never true for finite data
+}
+
+// The head kernels' own read pattern without their arithmetic: a wavefront per image, a lane
+// per cell (49 of 64 lanes), the cell's 30 channels as 30 four-byte loads 196 bytes apart,
+// four images per workgroup.  Against stream_read_kernel on the same bytes it prices the
+// access pattern itself.
+__global__ __launch_bounds__(256) void read_cells_kernel(const float* __restrict__ pred,
+                                                         float* __restrict__ sink, long long batch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long img = (long long)blockIdx.x * 4 + wave;
+    if (img >= batch || lane >= 49) return;
+    const float* p = pred + img * 1470 + lane;
+    float v[30];
+#pragma unroll
+    for (int ch = 0; ch < 30; ++ch) v[ch] = p[ch * 49];
+    float acc = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 30; ++ch) acc += v[ch];
+    if (acc == 1.2345e38f) *sink = acc;
+}
+
+// the same bytes brought in as the workgroup's contiguous block (4 images, 23,520 bytes) in
+// 16-byte loads, whole lines per wavefront instruction
+__global__ __launch_bounds__(256) void read_blocks_kernel(const float* __restrict__ pred,
+                                                          float* __restrict__ sink, long long batch) {
+    const long long img0 = (long long)blockIdx.x * 4;
+    const long long left = batch - img0;
+    const int n4 = (int)(left < 4 ? left : 4) * 1470 / 4;      // the block starts 16-byte aligned
+    const v4f* p = reinterpret_cast<const v4f*>(pred + img0 * 1470);
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    v4f v[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        v[u] = i < n4 ? p[i] : acc;
+    }
+#pragma unroll
+    for (int u = 0; u < 6; ++u) acc += v[u];
+    if (acc.x + acc.y + acc.z + acc.w == 1.2345e38f) *sink = acc.x;
+}
+
 }  // namespace
 
 extern "C" {
+
+// pattern 0: read_cells_kernel, pattern 1: read_blocks_kernel, on a (batch, 30, 7, 7) tensor
+int yhb_read_head(const float* pred, float* sink, long long batch, int pattern, void* stream) {
+    if (!pred || !sink || batch < 1 || ((uintptr_t)pred & 15)) return -1;
+    const unsigned grid = (unsigned)((batch + 3) / 4);
+    if (pattern == 0)
+        hipLaunchKernelGGL(read_cells_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, sink, batch);
+    else
+        hipLaunchKernelGGL(read_blocks_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, sink, batch);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// reads src[0 .. rbytes) and writes dst[0 .. wbytes) = src[0 .. wbytes), wbytes <= rbytes, both
+// multiples of 16 and the pointers 16-byte aligned: a streaming kernel that moves rbytes + wbytes,
+// the yardstick for a kernel with that traffic.  blocks: workgroups of 256 threads (0: 4096).
+int yhb_stream_rw(const void* src, size_t rbytes, void* dst, size_t wbytes, float* sink, int blocks,
+                  void* stream) {
+    if (!src || !dst || !sink || (rbytes & 15) || (wbytes & 15) || wbytes > rbytes ||
+        ((uintptr_t)dst & 15) || ((uintptr_t)src & 15))
+        return -1;
+    if (blocks <= 0) blocks = 4096;
+    hipLaunchKernelGGL((stream_rw_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const v4f*)src, (v4f*)dst, sink, (long long)(rbytes / 16), (long long)(wbytes / 16));
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
 
 // dst[0 .. nbytes) = src[0 .. nbytes); both 16-byte aligned, nbytes a multiple of 16.
 // blocks: workgroups of 256 threads (0: 16 per CU of a 256-CU part); unroll: 1, 2, 4 or 8;
