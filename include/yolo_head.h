@@ -255,11 +255,12 @@ int yh_box_area(const float* ltrb, float* out, int64_t n, void* stream);
  *   detections in one call, as eval.get_map takes them).  A NaN confidence ranks first
  *   (torch.argsort(descending=True) counts NaN as the largest value, eval.py:121).
  *   ap_out (n_classes) float64, map_out (1) float64 (eval.py:142, :149).
- *   workspace: yh_map_workspace_bytes(P, G) bytes, 256-byte aligned: sort keys and
- *   the temporary storage of the device radix sort.  The call queries the device
- *   (occupancy) on the host: keep it out of graph capture.  A small call (P <= 1024,
- *   G <= 2048, n_classes <= 1024) is one launch of one workgroup that sorts in LDS and
- *   does not touch the workspace; same bits either way.
+ *   workspace: yh_map_workspace_bytes(P, G) bytes, 256-byte aligned: two buffers of
+ *   64-bit sort words, the true-positive flags and the histogram of the library's own
+ *   device radix sort.  Like every other call it only enqueues kernels (legal under
+ *   graph capture).  A small call (P <= 1024, G <= 2048, n_classes <= 1024) is one
+ *   launch of one workgroup that sorts in LDS and does not touch the workspace; same
+ *   bits either way.
  */
 #define YH_MAP_MAX_ROWS 16777216
 size_t yh_map_workspace_bytes(int64_t P, int64_t G);
@@ -422,14 +423,14 @@ int yh_nms(const float* cand_ltrb, const float* cand_score, const int32_t* cand_
  * YH_MAX_CANDIDATES per image they forward to yh_decode_nms /
  * yh_decode_nms_linear (bias != NULL) / yh_nms, which keep an image's candidates in
  * LDS, and the workspace may be NULL.  Above, the candidates go through global
- * memory: boxes and 64-bit sort keys in the workspace, a device segmented radix
- * sort (one segment per image), then one workgroup per image that walks each class
- * in order against the rows it has already kept.  Same keep rule, row order and
- * bits as yh_decode_nms / yh_nms.
+ * memory: boxes and 64-bit sort keys in the workspace, the library's own segmented
+ * radix sort (one segment per image, stable, on the class and score bits), then one
+ * workgroup per image that walks each class in order against the rows it has already
+ * kept.  Same keep rule, row order and bits as yh_decode_nms / yh_nms.
  *   workspace: yh_nms_workspace_bytes(batch, N, own_boxes) bytes, 256-byte aligned;
  *   N = S*S*Bx and own_boxes = 1 for yh_decode_nms_ws, own_boxes = 0 for yh_nms_ws
- *   (0 bytes when N <= YH_MAX_CANDIDATES).  These calls query the device on the
- *   host (sort configuration): keep them out of graph capture.
+ *   (0 bytes when N <= YH_MAX_CANDIDATES).  Launch-only like every other call
+ *   (legal under graph capture).
  */
 size_t yh_nms_workspace_bytes(int64_t batch, int N, int own_boxes);
 int yh_decode_nms_ws(const float* pred, const float* bias, float* dets, int32_t* keep_count,

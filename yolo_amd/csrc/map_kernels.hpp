@@ -4,9 +4,9 @@
 //   2  one lane per prediction: true-positive flag (IoU against the ground truths
 //      of its class, scaled by 8 as eval.py:99 does) -> the class index of a true
 //      positive, else -1; and its sort key, the confidence as an ordered integer
-//   3  device radix sort of (key, index), descending and stable: the
-//      confidence-descending order of eval.py:121 with equal confidences in index
-//      order (rocPRIM, caller-provided temporary storage)
+//   3  device radix sort (radix_sort.hpp) of 64-bit words -- the inverted key in the high
+//      half, the row number in the low half -- on the high half, ascending and stable: the
+//      confidence-descending order of eval.py:121 with equal confidences in row order
 //   4  one workgroup per class: prefix count of that class's true positives over
 //      the ranked list, precision/recall in fp64 and the 11 recall-threshold maxima
 //   5  one lane: the mean over classes in class order (the reference's own
@@ -24,32 +24,31 @@ __device__ __forceinline__ int map_class_index(float clsf, int n_classes) {
     return ((float)ci == clsf && ci >= 0 && ci < n_classes) ? ci : -1;
 }
 
+// sort word of a ground truth: its class (0xFFFF when it has none: n_classes <= 65,535) above
+// its row number
 __global__ __launch_bounds__(256) void map_gt_keys_kernel(const float* __restrict__ gt, long long G,
                                                           int n_classes,
-                                                          unsigned int* __restrict__ keys,
-                                                          unsigned int* __restrict__ idx) {
+                                                          unsigned long long* __restrict__ words) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
     const int ci = map_class_index(gt[g * 5 + 4], n_classes);
-    keys[g] = ci < 0 ? 0xFFFFFFFFu : (unsigned int)ci;
-    idx[g] = (unsigned int)g;
+    words[g] = ((unsigned long long)(ci < 0 ? 0xFFFFu : (unsigned int)ci) << 32) | (unsigned int)g;
 }
 
 // eval.py:96-100: a prediction is a true positive when ANY ground truth of its class
 // has 8 * IoU(gt, pred) >= threshold.  A prediction whose class is not an integer
 // in [0, n_classes) belongs to no class's list (eval.py:132 compares with the loop
 // index), so its flag is never looked at.
-// SORTED: gkeys/gidx are the ground truths' classes in ascending order and their
-// row numbers; else the ground truths pass through LDS, 256 at a time, and the
+// SORTED: gsorted holds the ground truths' sort words in ascending order (class in the high
+// half, row number in the low half); else the ground truths pass through LDS, 256 at a time, and the
 // SL wavefront-aligned slices of a workgroup (256 / SL predictions each) share the
 // scan: slice s takes every SL-th ground truth, the flags are OR-ed in LDS.  Few
 // predictions then still fill the machine.
 template <bool SORTED, int SL>
 __global__ __launch_bounds__(256) void map_tp_key_kernel(
     const float* __restrict__ pred, const float* __restrict__ gt, long long P, long long G,
-    int n_classes, float iou_thresh, const unsigned int* __restrict__ gkeys,
-    const unsigned int* __restrict__ gidx, int* __restrict__ tpcls,
-    unsigned int* __restrict__ keys, unsigned int* __restrict__ idx) {
+    int n_classes, float iou_thresh, const unsigned long long* __restrict__ gsorted,
+    int* __restrict__ tpcls, unsigned long long* __restrict__ words) {
     constexpr int PB = 256 / SL;                       // predictions per workgroup
     const int pl = threadIdx.x % PB, sl = threadIdx.x / PB;
     const long long p = (long long)blockIdx.x * PB + pl;
@@ -70,10 +69,10 @@ __global__ __launch_bounds__(256) void map_tp_key_kernel(
             long long lo = 0, hi = G;
             while (lo < hi) {
                 const long long mid = (lo + hi) >> 1;
-                if (gkeys[mid] < (unsigned int)ci) lo = mid + 1; else hi = mid;
+                if ((unsigned int)(gsorted[mid] >> 32) < (unsigned int)ci) lo = mid + 1; else hi = mid;
             }
-            for (long long g = lo; g < G && gkeys[g] == (unsigned int)ci; ++g) {
-                const float* gr = gt + (long long)gidx[g] * 5;
+            for (long long g = lo; g < G && (unsigned int)(gsorted[g] >> 32) == (unsigned int)ci; ++g) {
+                const float* gr = gt + (long long)(unsigned int)gsorted[g] * 5;
                 const Box gb = {gr[0], gr[1], gr[2], gr[3]};
                 tp = tp || (iou_pair(gb, pb) * 8.0f >= iou_thresh);
             }
@@ -106,18 +105,19 @@ __global__ __launch_bounds__(256) void map_tp_key_kernel(
     if (live) {
         tpcls[p] = tp ? ci : -1;
         // descending sort key; -0 counts as +0 and a NaN confidence ranks first, above +inf,
-        // as torch.argsort(descending=True) ranks it (eval.py:121)
-        keys[p] = conf != conf ? 0xFFFFFFFFu : float_to_ordered(conf + 0.0f);
-        idx[p] = (unsigned int)p;
+        // as torch.argsort(descending=True) ranks it (eval.py:121).  The word is sorted
+        // ascending on its high half: the inverted key
+        const unsigned int ckey = conf != conf ? 0xFFFFFFFFu : float_to_ordered(conf + 0.0f);
+        words[p] = ((unsigned long long)(~ckey) << 32) | (unsigned int)p;
     }
 }
 
 // ranked[k] = class of the k-th ranked prediction if it is a true positive, else -1
 __global__ __launch_bounds__(256) void map_gather_kernel(const int* __restrict__ tpcls,
-                                                         const unsigned int* __restrict__ order,
+                                                         const unsigned long long* __restrict__ order,
                                                          long long P, int* __restrict__ ranked) {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < P) ranked[k] = tpcls[order[k]];
+    if (k < P) ranked[k] = tpcls[(unsigned int)order[k]];
 }
 
 // mean of the 11 interpolated precisions as np.sum forms it (eight pairwise-combined
@@ -151,11 +151,11 @@ __device__ __forceinline__ void map_fold_maxima(long long tp, long long k, long 
 // count stays and the precision only falls, so nothing else can raise a maximum
 // -- and keeps the 11 recall-threshold maxima per lane; positive doubles order as
 // integers, so the lanes merge theirs with an LDS integer max.
-// order[k] = row of the prediction ranked k-th; `ranked` (may be null) is the
-// gathered list tpcls[order[k]], used when given.
+// The low half of order[k] is the row of the prediction ranked k-th; `ranked` (may be null)
+// is the gathered list tpcls[row], used when given.
 constexpr int MAP_AP_THREADS = 1024;
 __global__ __launch_bounds__(MAP_AP_THREADS) void map_ap_kernel(
-    const int* __restrict__ tpcls, const unsigned int* __restrict__ order,
+    const int* __restrict__ tpcls, const unsigned long long* __restrict__ order,
     const int* __restrict__ ranked, long long P, long long G, double* __restrict__ ap_out) {
     constexpr int NW = MAP_AP_THREADS / 64;
     __shared__ long long wcnt[NW];
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(MAP_AP_THREADS) void map_ap_kernel(
     const long long k1 = k0 + span < P ? k0 + span : P;
     auto is_tp = [&](long long k) -> bool {
         if (k >= k1) return false;
-        return (ranked ? ranked[k] : tpcls[order[k]]) == c;
+        return (ranked ? ranked[k] : tpcls[(unsigned int)order[k]]) == c;
     };
     const bool short_span = span <= 256;     // the flags of pass 1 stay in registers for pass 2
     bool f0 = false, f1 = false, f2 = false, f3 = false;

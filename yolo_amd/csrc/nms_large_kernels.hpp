@@ -3,7 +3,7 @@
 //   1  one lane per cell (or per supplied candidate): the candidate's box to a
 //      box array and its 64-bit sort key (class | inverted score | flat index, the
 //      key nms_kernel ranks by; all ones for a candidate that is not valid)
-//   2  device segmented radix sort of the keys, one segment per image (rocPRIM)
+//   2  segmented radix sort of the keys, one segment per image (radix_sort.hpp)
 //   3  one workgroup per image walks the sorted keys in chunks of up to 64
 //      candidates of one class: a chunk is first tested against the rows already
 //      kept for that class -- they are the tail of the output itself, read back
@@ -68,12 +68,6 @@ __global__ __launch_bounds__(256) void nms_large_cand_keys_kernel(
         keys[g] = valid ? nms_key(cls, score, (int)(g % N)) : ~0ull;
     }
 }
-
-// begin / end of image i's segment in the key array
-struct NmsSegmentOffset {
-    unsigned int n, add;
-    __host__ __device__ unsigned int operator()(unsigned int i) const { return (i + add) * n; }
-};
 
 // scores: the candidates' scores as supplied (bit-exact copy into the rows), or
 // null: the score is taken back out of the key.

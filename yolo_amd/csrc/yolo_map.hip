@@ -1,16 +1,13 @@
-// yh_map_11point and its workspace size: the mAP entry point of
-// include/yolo_head.h, in a translation unit of its own because it pulls in the
-// rocPRIM device radix sort.
+// yh_map_11point and its workspace size: the mAP entry point of include/yolo_head.h.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
 
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
-
 #include "../../include/yolo_head.h"
 #include "map_kernels.hpp"
+#include "radix_sort.hpp"
 
 namespace {
 
@@ -21,44 +18,27 @@ inline int launch_status() {
     return e == hipSuccess ? YH_OK : (int)e;
 }
 
-// temporary storage rocPRIM wants for a pair sort of n 32-bit keys (a host-side query)
-size_t sort_temp_bytes(size_t n) {
-    if (n == 0) return 0;
-    size_t bytes = 0;
-    unsigned int* k = nullptr;
-    const hipError_t e = rocprim::radix_sort_pairs_desc(nullptr, bytes, k, k, k, k, n, 0, 32, (hipStream_t)0);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        return up256(16 * n + (1u << 20));   // no device to ask: a generous bound
-    }
-    return bytes;
-}
-
+// two buffers of sort words for the predictions (and for the ground truths when they are
+// sorted by class), the true-positive classes, and the histogram of the radix sort
 struct MapLayout {
-    size_t keys_in, keys_out, idx_in, idx_out, tpcls, gkeys_in, gkeys_out, gidx_in, gidx_out, temp,
-        temp_bytes, total;
+    size_t words_a, words_b, tpcls, gwords_a, gwords_b, hist, total;
 };
 
 MapLayout map_layout(int64_t P, int64_t G) {
     MapLayout l = {};
     size_t off = 0;
-    const size_t p4 = up256((size_t)(P < 1 ? 1 : P) * 4);
-    l.keys_in = off; off += p4;
-    l.keys_out = off; off += p4;
-    l.idx_in = off; off += p4;
-    l.idx_out = off; off += p4;
-    l.tpcls = off; off += p4;
+    const size_t p8 = up256((size_t)(P < 1 ? 1 : P) * 8);
+    l.words_a = off; off += p8;
+    l.words_b = off; off += p8;
+    l.tpcls = off; off += up256((size_t)(P < 1 ? 1 : P) * 4);
     const bool sorted_gt = G > yh::MAP_GT_DIRECT;
     if (sorted_gt) {
-        const size_t g4 = up256((size_t)G * 4);
-        l.gkeys_in = off; off += g4;
-        l.gkeys_out = off; off += g4;
-        l.gidx_in = off; off += g4;
-        l.gidx_out = off; off += g4;
+        const size_t g8 = up256((size_t)G * 8);
+        l.gwords_a = off; off += g8;
+        l.gwords_b = off; off += g8;
     }
-    const size_t tp = sort_temp_bytes((size_t)P), tg = sorted_gt ? sort_temp_bytes((size_t)G) : 0;
-    l.temp_bytes = up256(tp > tg ? tp : tg);
-    l.temp = off; off += l.temp_bytes;
+    const size_t hp = yh::radix_hist_words(1, P < 1 ? 1 : P), hg = sorted_gt ? yh::radix_hist_words(1, G) : 0;
+    l.hist = off; off += up256((hp > hg ? hp : hg) * 4);
     l.total = off;
     return l;
 }
@@ -86,60 +66,58 @@ int yh_map_11point(const float* pred, const float* gt, int64_t P, int64_t G, int
         return YH_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
-    unsigned int* keys_in = (unsigned int*)(ws + l.keys_in);
-    unsigned int* keys_out = (unsigned int*)(ws + l.keys_out);
-    unsigned int* idx_in = (unsigned int*)(ws + l.idx_in);
-    unsigned int* idx_out = (unsigned int*)(ws + l.idx_out);
+    unsigned long long* words_a = (unsigned long long*)(ws + l.words_a);
+    unsigned long long* words_b = (unsigned long long*)(ws + l.words_b);
+    unsigned int* hist = (unsigned int*)(ws + l.hist);
     int* tpcls = (int*)(ws + l.tpcls);
-    void* temp = ws + l.temp;
-    size_t temp_bytes = l.temp_bytes;
     if (P <= yh::MAP_SMALL_P && G <= yh::MAP_GT_DIRECT && n_classes <= yh::MAP_SMALL_CLASSES) {
         // a small call: everything in one workgroup, one launch (the workspace is not used)
         hipLaunchKernelGGL(yh::map_small_kernel, dim3(1), dim3(yh::MAP_SMALL_P), 0, st, pred, gt, (int)P,
                            (int)G, n_classes, iou_thresh, ap_out, map_out);
         return launch_status();
     }
+    const unsigned long long* order = words_a;   // the ranked sort words (low half: the row)
+    unsigned long long* spare = words_b;         // the buffer the sort leaves free
     if (P > 0) {
         const unsigned grid = (unsigned)((P + 255) / 256);
         if (G > yh::MAP_GT_DIRECT) {
-            unsigned int* gk_in = (unsigned int*)(ws + l.gkeys_in);
-            unsigned int* gk_out = (unsigned int*)(ws + l.gkeys_out);
-            unsigned int* gi_in = (unsigned int*)(ws + l.gidx_in);
-            unsigned int* gi_out = (unsigned int*)(ws + l.gidx_out);
+            unsigned long long* ga = (unsigned long long*)(ws + l.gwords_a);
+            unsigned long long* gb = (unsigned long long*)(ws + l.gwords_b);
             hipLaunchKernelGGL(yh::map_gt_keys_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st,
-                               gt, (long long)G, n_classes, gk_in, gi_in);
+                               gt, (long long)G, n_classes, ga);
             if (const int rc = launch_status()) return rc;
-            const hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, gk_in, gk_out, gi_in,
-                                                           gi_out, (size_t)G, 0, 32, st);
-            if (e != hipSuccess) return (int)e;
+            int err = 0;
+            // classes are below 65,536: two passes over bits 32..47
+            const unsigned long long* gsorted = yh::radix_sort_u64(ga, gb, hist, 1, G, 32, 48, st, &err);
+            if (!gsorted) return err;
             hipLaunchKernelGGL((yh::map_tp_key_kernel<true, 1>), dim3(grid), dim3(256), 0, st, pred, gt,
-                               (long long)P, (long long)G, n_classes, iou_thresh, gk_out, gi_out, tpcls,
-                               keys_in, idx_in);
+                               (long long)P, (long long)G, n_classes, iou_thresh, gsorted, tpcls, words_a);
         } else if (P <= 16384) {
             // few predictions: four slices of a workgroup share the scan of the ground truths
             hipLaunchKernelGGL((yh::map_tp_key_kernel<false, 4>), dim3((unsigned)((P + 63) / 64)), dim3(256),
                                0, st, pred, gt, (long long)P, (long long)G, n_classes, iou_thresh, nullptr,
-                               nullptr, tpcls, keys_in, idx_in);
+                               tpcls, words_a);
         } else {
             hipLaunchKernelGGL((yh::map_tp_key_kernel<false, 1>), dim3(grid), dim3(256), 0, st, pred, gt,
-                               (long long)P, (long long)G, n_classes, iou_thresh, nullptr, nullptr, tpcls,
-                               keys_in, idx_in);
+                               (long long)P, (long long)G, n_classes, iou_thresh, nullptr, tpcls, words_a);
         }
         if (const int rc = launch_status()) return rc;
-        const hipError_t e = rocprim::radix_sort_pairs_desc(temp, temp_bytes, keys_in, keys_out, idx_in,
-                                                            idx_out, (size_t)P, 0, 32, st);
-        if (e != hipSuccess) return (int)e;
+        int err = 0;
+        unsigned long long* sorted = yh::radix_sort_u64(words_a, words_b, hist, 1, P, 32, 64, st, &err);
+        if (!sorted) return err;
+        order = sorted;
+        spare = sorted == words_a ? words_b : words_a;
     }
-    // a long ranked list is gathered once (into the unsorted keys' place, free after the sort)
+    // a long ranked list is gathered once (into the buffer the sort leaves free)
     int* ranked = nullptr;
     if (P > 65536) {
-        ranked = (int*)keys_in;
+        ranked = (int*)spare;
         hipLaunchKernelGGL(yh::map_gather_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st,
-                           tpcls, idx_out, (long long)P, ranked);
+                           tpcls, order, (long long)P, ranked);
         if (const int rc = launch_status()) return rc;
     }
     hipLaunchKernelGGL(yh::map_ap_kernel, dim3((unsigned)n_classes), dim3(yh::MAP_AP_THREADS), 0, st,
-                       tpcls, idx_out, ranked, (long long)P, (long long)G, ap_out);
+                       tpcls, order, ranked, (long long)P, (long long)G, ap_out);
     if (const int rc = launch_status()) return rc;
     hipLaunchKernelGGL(yh::map_mean_kernel, dim3(1), dim3(64), 0, st, ap_out, n_classes, map_out);
     return launch_status();

@@ -1,6 +1,6 @@
 // yh_decode_nms_ws / yh_nms_ws: the NMS entry points with a workspace, which take
-// more candidates per image than the LDS-resident kernels (global-memory path with
-// the rocPRIM segmented radix sort).  Up to YH_MAX_CANDIDATES they forward to
+// more candidates per image than the LDS-resident kernels (global-memory path with a
+// segmented radix sort, one segment per image).  Up to YH_MAX_CANDIDATES they forward to
 // yh_decode_nms / yh_decode_nms_linear / yh_nms and need no workspace.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -8,12 +8,9 @@
 
 #include <cstring>
 
-#include <rocprim/device/device_segmented_radix_sort.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
-
 #include "../../include/yolo_head.h"
 #include "nms_large_kernels.hpp"
+#include "radix_sort.hpp"
 
 namespace {
 
@@ -24,66 +21,44 @@ inline int launch_status() {
     return e == hipSuccess ? YH_OK : (int)e;
 }
 
-using OffsetIt = rocprim::transform_iterator<rocprim::counting_iterator<unsigned int>,
-                                             yh::NmsSegmentOffset, unsigned int>;
-
-// images sorted per rocPRIM call: its sizes are 32-bit
-inline int64_t images_per_sort(int64_t batch, int N) {
-    int64_t g = ((int64_t)1 << 30) / N;
-    if (g < 1) g = 1;
-    return g < batch ? g : batch;
-}
-
-hipError_t sort_images(void* temp, size_t& temp_bytes, const unsigned long long* in,
-                       unsigned long long* out, int64_t images, int N, hipStream_t st) {
-    const OffsetIt begin(rocprim::counting_iterator<unsigned int>(0), yh::NmsSegmentOffset{(unsigned)N, 0});
-    const OffsetIt end(rocprim::counting_iterator<unsigned int>(0), yh::NmsSegmentOffset{(unsigned)N, 1});
-    return rocprim::segmented_radix_sort_keys(temp, temp_bytes, in, out, (unsigned int)(images * N),
-                                              (unsigned int)images, begin, end, 0, 64, st);
-}
-
-size_t sort_temp_bytes(int64_t batch, int N) {
-    size_t bytes = 0;
-    const hipError_t e = sort_images(nullptr, bytes, nullptr, nullptr, images_per_sort(batch, N), N, 0);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        return up256((size_t)images_per_sort(batch, N) * N * 16 + (1u << 20));   // no device to ask
-    }
-    return up256(bytes);
-}
-
 struct LargeLayout {
-    size_t keys_in, keys_out, boxes, temp, temp_bytes, total;
+    size_t keys_a, keys_b, boxes, hist, total;
 };
 
 LargeLayout large_layout(int64_t batch, int N, bool own_boxes) {
     LargeLayout l = {};
     size_t off = 0;
     const size_t k8 = up256((size_t)batch * N * 8);
-    l.keys_in = off; off += k8;
-    l.keys_out = off; off += k8;
+    l.keys_a = off; off += k8;
+    l.keys_b = off; off += k8;
     if (own_boxes) { l.boxes = off; off += up256((size_t)batch * N * 16); }
-    l.temp_bytes = sort_temp_bytes(batch, N);
-    l.temp = off; off += l.temp_bytes;
+    l.hist = off; off += up256(yh::radix_hist_words(batch, N) * 4);
     l.total = off;
     return l;
 }
 
+// The keys are class | inverted score | flat index and lie in flat-index order, so a stable sort
+// on the class and score bits alone orders them: four passes for the score and one for every
+// eight bits the classes take (class_bits: an upper bound on the bits of a valid class).  Keys
+// that are not valid are all ones: the largest digit in every pass, so they come out last.
 int sort_and_suppress(const LargeLayout& l, char* ws, const float4* boxes, const float* scores,
                       float* dets, int32_t* keep_count, int32_t* keep_idx, int64_t batch, int N,
-                      float iou_thresh, hipStream_t st) {
-    const unsigned long long* kin = (const unsigned long long*)(ws + l.keys_in);
-    unsigned long long* kout = (unsigned long long*)(ws + l.keys_out);
-    const int64_t per = images_per_sort(batch, N);
-    for (int64_t i0 = 0; i0 < batch; i0 += per) {
-        const int64_t n = batch - i0 < per ? batch - i0 : per;
-        size_t tb = l.temp_bytes;
-        const hipError_t e = sort_images(ws + l.temp, tb, kin + i0 * N, kout + i0 * N, n, N, st);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(yh::nms_large_kernel, dim3((unsigned)batch), dim3(256), 0, st, kout, boxes, scores,
+                      int class_bits, float iou_thresh, hipStream_t st) {
+    const int bit_hi = 48 + 8 * ((class_bits + 7) / 8);
+    int err = 0;
+    const unsigned long long* sorted =
+        yh::radix_sort_u64((unsigned long long*)(ws + l.keys_a), (unsigned long long*)(ws + l.keys_b),
+                           (unsigned int*)(ws + l.hist), batch, N, 16, bit_hi, st, &err);
+    if (!sorted) return err;
+    hipLaunchKernelGGL(yh::nms_large_kernel, dim3((unsigned)batch), dim3(256), 0, st, sorted, boxes, scores,
                        dets, keep_count, keep_idx, N, iou_thresh);
     return launch_status();
+}
+
+inline int bits_for(int n_values) {     // bits that hold 0 .. n_values - 1
+    int b = 0;
+    while ((1 << b) < n_values) ++b;
+    return b;
 }
 
 }  // namespace
@@ -120,7 +95,7 @@ int yh_decode_nms_ws(const float* pred, const float* bias, float* dets, int32_t*
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
     float4* boxes = (float4*)(ws + l.boxes);
-    unsigned long long* keys = (unsigned long long*)(ws + l.keys_in);
+    unsigned long long* keys = (unsigned long long*)(ws + l.keys_a);
     int64_t blocks = (batch * S * S + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     const float cellf = (float)(img_size / S), imgf = (float)img_size;
@@ -134,7 +109,7 @@ int yh_decode_nms_ws(const float* pred, const float* bias, float* dets, int32_t*
                            conf_thresh);
     if (const int rc = launch_status()) return rc;
     return sort_and_suppress(l, ws, boxes, nullptr, dets, keep_count, keep_idx, batch, (int)N,
-                             iou_thresh, st);
+                             bits_for(C), iou_thresh, st);
 }
 
 int yh_nms_ws(const float* cand_ltrb, const float* cand_score, const int32_t* cand_cls,
@@ -161,11 +136,11 @@ int yh_nms_ws(const float* cand_ltrb, const float* cand_score, const int32_t* ca
     int64_t blocks = (batch * N + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(yh::nms_large_cand_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
-                       cand_score, cand_cls, cand_present, (unsigned long long*)(ws + l.keys_in),
+                       cand_score, cand_cls, cand_present, (unsigned long long*)(ws + l.keys_a),
                        (long long)batch, N, conf_thresh);
     if (const int rc = launch_status()) return rc;
     return sort_and_suppress(l, ws, (const float4*)cand_ltrb, cand_score, dets, keep_count, keep_idx,
-                             batch, N, iou_thresh, st);
+                             batch, N, 15, iou_thresh, st);      // classes up to 32,767
 }
 
 }  // extern "C"
