@@ -135,6 +135,20 @@ int yh_decode_nms_nhwc(const float* pred, float* dets, int32_t* keep_count, int3
                        int C, int img_size, void* stream);
 
 /*
+ * The loss terms of every image by itself (forward only): per_image (batch, 4) receives the
+ * coordinate, confidence and class sums of image b and their total -- the per-image values
+ * whose sum over the batch, divided by it, is what get_loss returns (model.py:296-317; the
+ * reference itself only forms the batch sums).  One wavefront per image and a wavefront
+ * reduction when S*S <= 64, a workgroup per image above; fixed summation order, so the values
+ * are reproducible from run to run.  The arithmetic per cell is that of yh_loss_fwd_bwd; the
+ * order of the additions differs, so the batch totals agree to rounding, not to the bit.
+ * Alignment: gt_xywh 16 bytes, the others 4.
+ */
+int yh_loss_per_image(const float* pred, const float* gt_xywh, const float* gt_cls,
+                      const uint8_t* obj_mask, float* per_image, int64_t batch, int S, int Bx, int C,
+                      int img_size, float lambda_coord, float lambda_noobj, void* stream);
+
+/*
  * The two halves of yh_loss_fwd_bwd as separate launches, for callers that put
  * the scalar reduction on another stream (nothing downstream of the gradient
  * depends on it) or log the loss on the device.

@@ -608,3 +608,31 @@ def test_finalize_on_a_side_stream_back_to_back(dev):
         torch.cuda.synchronize()
         for g, w in zip(got, want):
             assert torch.equal(g, w)
+
+
+@pytest.mark.parametrize("S,Bx,C,batch", [(7, 2, 20, 67), (14, 5, 80, 9), (3, 1, 5, 130), (9, 3, 24, 5),
+                                          (64, 16, 8, 2)])
+def test_per_image_loss_terms(dev, S, Bx, C, batch):
+    """yh_loss_per_image: the coordinate, confidence and class sums of every image by itself
+    against the oracle run on that image alone (model.py:224-294; rtol 1e-5), and their sum
+    over the batch against the fused kernel's batch sums."""
+    img = 32 * S
+    head = YOLOv1Head(img_size=img, n_cells=S, n_bboxes=Bx, n_classes=C)
+    pred, gx, gc, om = synth.make_inputs(batch, S, Bx, C, img, seed=90 + S)
+    om[0] = False                                                # an image without any object
+    gx[0], gc[0] = 0.0, 0.0
+    d = [t.to(dev) for t in (pred, gx, gc, om)]
+    per = head.get_loss_per_image(*d)
+    assert per.shape == (batch, 4)
+    again = head.get_loss_per_image(*d)
+    assert torch.equal(per, again)                               # fixed summation order
+    hp = dict(n_cells=S, n_bboxes=Bx, n_classes=C, img_size=img)
+    want = torch.zeros(batch, 4)
+    for b in range(min(batch, 12)):
+        c, f, k, _ = ref_cpu.loss_terms(pred[b:b + 1], gx[b:b + 1], gc[b:b + 1], om[b:b + 1], **hp)
+        want[b] = torch.stack([c, f, k, c + f + k])
+    n = min(batch, 12)
+    torch.testing.assert_close(per[:n].cpu(), want[:n], rtol=1e-5, atol=1e-6)
+    assert per[0, 0].item() == 0.0 and per[0, 2].item() == 0.0   # no object: only the no-object confidence term
+    terms, _ = head.loss_fwd_bwd(*d)
+    torch.testing.assert_close(per.double().sum(0).float().cpu(), terms[:4].cpu(), rtol=1e-5, atol=0)

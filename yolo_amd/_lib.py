@@ -61,6 +61,8 @@ SIGNATURES = {
                                      c_float, c_float, c_float, c_void_p]),
     "yh_decode_nms_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
                                    c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "yh_loss_per_image": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                  c_int, c_int, c_float, c_float, c_void_p]),
     "yh_loss_partials": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_size_t, c_int64, c_int, c_int, c_int, c_int, c_float, c_float,
                                  c_float, c_void_p]),

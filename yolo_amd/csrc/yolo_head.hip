@@ -14,6 +14,7 @@
 #include "loss_kernels.hpp"
 #include "nms_kernels.hpp"
 #include "step_kernels.hpp"
+#include "per_image_kernels.hpp"
 #include "target_kernels.hpp"
 #include "box_kernels.hpp"
 
@@ -922,5 +923,20 @@ int yh_head_step_pipelined(const float* pred, const float* gt_xywh, const float*
                             (hipStream_t)stream);
 }
 
-}  // extern "C"
+int yh_loss_per_image(const float* pred, const float* gt_xywh, const float* gt_cls,
+                      const uint8_t* obj_mask, float* per_image, int64_t batch, int S, int Bx, int C,
+                      int img_size, float lambda_coord, float lambda_noobj, void* stream) {
+    if (const int rc = check_shape(batch, S, Bx, C, img_size)) return rc;
+    if (batch == 0) return YH_OK;
+    if (!pred || !gt_xywh || !gt_cls || !obj_mask || !per_image) return YH_ERR_NULL;
+    if (!aligned(gt_xywh, 16) || !aligned(pred, 4) || !aligned(gt_cls, 4) || !aligned(per_image, 4))
+        return YH_ERR_ALIGN;
+    if (isnan(lambda_coord) || isnan(lambda_noobj)) return YH_ERR_ARG;
+    const int ipb = S * S <= 64 ? 4 : 1;
+    hipLaunchKernelGGL(yh::loss_per_image_kernel, dim3((unsigned)((batch + ipb - 1) / ipb)), dim3(256), 0,
+                       (hipStream_t)stream, pred, gt_xywh, gt_cls, obj_mask, per_image, (long long)batch, S,
+                       Bx, C, ipb, (float)(img_size / S), (float)img_size, lambda_coord, lambda_noobj);
+    return launch_status();
+}
 
+}  // extern "C"

@@ -345,7 +345,7 @@ class YOLOv1Head(nn.Module):
         state[1] = phase
         return grad
 
-    def _check_step_args(self, out, gt_norm_xywh, gt_cls_prob, obj_mask, mode, rows):
+    def _check_step_args(self, out, gt_norm_xywh, gt_cls_prob, obj_mask, mode, rows, limit=True):
         out = self._check_out(out.detach())
         bsz, n = out.shape[0], self.n_grid
         _need(gt_norm_xywh, "gt_norm_xywh", torch.float32, (bsz, n, 1, 4))
@@ -358,7 +358,7 @@ class YOLOv1Head(nn.Module):
             if t.device != out.device:
                 raise ValueError(f"{name}: on {t.device}, out is on {out.device}")
         nn_ = n * self.n_bboxes
-        if nn_ > _lib.YH_MAX_CANDIDATES:
+        if limit and nn_ > _lib.YH_MAX_CANDIDATES:
             raise ValueError(f"head_step: up to {_lib.YH_MAX_CANDIDATES} candidates per image")
         nrows = nn_ if rows is None else int(rows)
         return out, obj_mask, bsz, nrows
@@ -663,6 +663,20 @@ class YOLOv1Head(nn.Module):
         terms, _ = self._launch_loss(self._check_out(out.detach()), gt_norm_xywh, gt_cls_prob,
                                      obj_mask, 1.0)
         return terms[0], terms[1], terms[2]
+
+    def get_loss_per_image(self, out, gt_norm_xywh, gt_cls_prob, obj_mask):
+        """The loss terms of every image by itself: (B, 4) = coordinate, confidence and class
+        sums and their total (not divided by anything); ``.sum(0) / B`` is what ``get_loss``
+        returns, to rounding (model.py:296-317 forms only the batch sums)."""
+        out, obj_mask, bsz, _ = self._check_step_args(out, gt_norm_xywh, gt_cls_prob, obj_mask,
+                                                      _lib.YH_MODE_REFERENCE, 1, limit=False)
+        per_image = torch.empty(bsz, 4, dtype=torch.float32, device=out.device)
+        with _on_device(out.device):
+            _lib.check(_lib.load().yh_loss_per_image(
+                out.data_ptr(), gt_norm_xywh.data_ptr(), gt_cls_prob.data_ptr(), obj_mask.data_ptr(),
+                per_image.data_ptr(), bsz, self.n_cells, self.n_bboxes, self.n_classes, self.img_size,
+                self.coord_coeff, self.noobj_coeff, _stream(out.device)))
+        return per_image
 
     def get_coordinate_loss(self, out, gt_norm_xywh, gt_cls_prob, obj_mask):
         """model.py:224-240 (the arguments are those get_loss has in scope)."""
