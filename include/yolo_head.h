@@ -389,9 +389,9 @@ int yh_decode_nms_rows(const float* pred, float* dets, int32_t* keep_count, int3
 
 /*
  * One call for both halves of a step on the same head tensor: yh_loss_fwd_bwd and
- * yh_decode_nms_rows, as a validation pass needs them together (the loss of
- * train.py:100-110 / model.py:296-317 and the detections of model.py:379-394 from one
- * forward pass).  At S = 7, Bx = 2, C = 20 in YH_MODE_REFERENCE (gt_cls and grad_pred
+ * yh_decode_nms_rows, as an evaluation pass needs them together (the validation loss of
+ * train.py:100-110 / model.py:296-317 and, for eval.get_map of eval.py:145, the detections
+ * of model.py:379-394 from one forward pass).  At S = 7, Bx = 2, C = 20 in YH_MODE_REFERENCE (gt_cls and grad_pred
  * 16-byte aligned) ONE kernel reads the head tensor once for both; every other case
  * enqueues the two launches one after the other.  All outputs -- grad_pred, loss_terms,
  * dets, keep_count, keep_idx -- are bit for bit those of the two separate calls.

@@ -64,3 +64,18 @@ def test_one_gpu_line_has_the_contract_keys(dev):
     assert all(v["timed_passes"] == 20 and v["warmup_passes"] == 3 for v in cb.values())
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
     assert line["config"]["workload"].startswith("YOLOv1 head S=7,B=2,C=20 batch 4096")
+
+
+def test_other_ways_to_run_the_step(dev):
+    """--step two-stream (the two kernels on two streams, as before the one-kernel step) and
+    --regime resident (one buffer set, served by the memory-side cache in part) still run and
+    say what they ran; the loss they log is the loss of the default run."""
+    base = ["--steps", "40", "--warmup", "4", "--measure", "step", "--prewarm-seconds", "0.05"]
+    fused = run_bench(base)
+    two = run_bench(base + ["--step", "two-stream"])
+    res = run_bench(base + ["--regime", "resident"])
+    assert fused["config"]["streams"] == 1 and "yh_head_step_pipelined" in fused["config"]["step"]
+    assert two["config"]["streams"] == 2 and "yh_loss_fwd_bwd_pipelined" in two["config"]["step"]
+    assert res["config"]["regime"].startswith("one resident buffer set") and "value_hbm_proper" not in res
+    assert fused["config"]["regime"].startswith("buffers rotate") and fused["value_hbm_proper"] == fused["value"]
+    assert fused["loss"] == two["loss"] == res["loss"]

@@ -95,7 +95,7 @@ def test_validation_under_inference_mode(dev):
 
 
 def test_evaluation_pass_matches_the_oracle(dev):
-    """examples/eval_step.py: postprocess -> pooled rows -> get_map, all on the device, against
+    """examples/eval_step.py: head_step (loss + detections) -> pooled rows -> get_map, all on the device, against
     the CPU oracle's post-processing and the reference's metric on the same rows."""
     import importlib.util
     import os
@@ -112,7 +112,12 @@ def test_evaluation_pass_matches_the_oracle(dev):
     head = YOLOv1Head()
     out = synth.make_pred(24, seed=4)
     ltrb, label, cnt = synth.make_gt_boxes(24, seed=5)
-    m, pred, gt = mod.evaluate(head, out.to(dev), ltrb.to(dev), label.to(dev), cnt.to(dev), 0.3, 0.5, 2.0)
+    m, pred, gt, loss = mod.evaluate(head, out.to(dev), ltrb.to(dev), label.to(dev), cnt.to(dev), 0.3, 0.5, 2.0)
+    # the validation loss of the same launch (train.py:100-110) against the oracle on the
+    # oracle's own target encoding
+    gx, gc, om = ref_cpu.encode_targets(ltrb, label, cnt)
+    want_loss = ref_cpu.get_loss(out, gx, gc, om)
+    assert abs(loss.item() - want_loss.item()) <= 1e-5 * abs(want_loss.item())
     wd, wc, _ = ref_cpu.postprocess(out, 0.3, 0.5, mode=0)
     want_pred = np.concatenate([np.asarray(wd)[b, : int(wc[b])] for b in range(24)], axis=0)
     # the candidates' boxes and scores are decoded on the GPU (exp within a few ulp of the

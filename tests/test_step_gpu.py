@@ -1,6 +1,7 @@
 """yh_head_step / yh_head_step_pipelined: the loss forward+backward and decode+NMS of one
-head tensor in one call (model.py:296-317 and :379-394 on the same forward output, as the
-validation loop of train.py:100-110 needs them).  At S=7, Bx=2, C=20 in reference mode one
+head tensor in one call (model.py:296-317 and :379-394 on the same forward output: the
+validation loss of train.py:100-110 plus the detections an evaluation feeds to eval.get_map,
+eval.py:145).  At S=7, Bx=2, C=20 in reference mode one
 kernel reads the head tensor once for both; every output must be the BITS of the two
 separate entry points, and so must the oracle's parity carry over unchanged."""
 import numpy as np

@@ -1,7 +1,8 @@
 // One launch for both halves of a step on the head tensor: the loss forward + backward
 // (model.py:296-317, the gradient of loss.backward(), train.py:89-93) and decode +
-// confidence threshold + per-class NMS in reference mode (model.py:379-394), as a
-// validation pass computes them together on the same output (train.py:100-110).  The two
+// confidence threshold + per-class NMS in reference mode (model.py:379-394): what an
+// evaluation pass wants from one forward output -- the validation loss of train.py:100-110
+// and the detections that go to eval.get_map (eval.py:145).  The two
 // kernels it replaces (loss_fwd_bwd_kernel, nms_kernel<64, 1, ...>) each read the head
 // tensor -- the loss kernel in effect all of it: the confidence channels of every cell and
 // every channel of the cells with an object touch nearly every 128-byte line -- so one

@@ -366,8 +366,9 @@ class YOLOv1Head(nn.Module):
     def head_step(self, out, gt_norm_xywh, gt_cls_prob, obj_mask, conf_thresh=0.5, iou_thresh=0.5,
                   mode=_lib.YH_MODE_REFERENCE, global_batch=None, rows: Optional[int] = None,
                   return_idx=False):
-        """Loss forward + backward AND decode + NMS of the same head tensor in one call (a
-        validation pass wants both from one forward, train.py:100-110): returns
+        """Loss forward + backward AND decode + NMS of the same head tensor in one call (an
+        evaluation wants the validation loss of train.py:100-110 and the detections for
+        eval.get_map, eval.py:145, from one forward pass): returns
         ``(terms, grad, dets, count[, keep_idx])``, each the bits ``loss_fwd_bwd`` and
         ``postprocess(..., rows=rows)`` return.  At S=7, Bx=2, C=20 in reference mode one
         kernel reads the head tensor once for both."""
