@@ -1033,18 +1033,20 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         // A workgroup per image.  A class segment is cut into blocks of 64 members.  The
         // pairs (earlier member i, later member p) inside a block, of all blocks, are
         // spread evenly over the threads, whatever the block lengths; a pair whose IoU
-        // exceeds the threshold sets bit (index of p in the block) in the word of i.  One
-        // lane per block then walks its members in order: a member still alive kills the
-        // members in its word.  No barrier per member, and every lane of the pair loop has
-        // work.  A segment of more than 64 members takes a round per block: after the walk
-        // of its k-th block the members of the later blocks test themselves against that
-        // block's survivors (a member killed this way clears its own word, so it kills
-        // nobody when its block is walked).  Most images need one round.
+        // exceeds the threshold sets bit (index of i in the block) in the word of p -- the
+        // word belongs to the lane that tests p's pairs, so it is filled with plain stores.
+        // One lane per block then walks its members in order: a member stays when no member
+        // that stayed before it is in its word.  No barrier per member, and every lane of the
+        // pair loop has work.  A segment of more than 64 members takes a round per block:
+        // after the walk of its k-th block the members of the later blocks test themselves
+        // against that block's survivors (a member suppressed this way gets its OWN bit set
+        // in its word, which the walk of its block reads as "gone").  Most images need one
+        // round.
         const int nrounds = (maxpos >> 6) + 1;
         unsigned long long* kills = keys;     // the keys are not needed any more
         // The pair phase works on ROWS: a later member p of a block against its r earlier
         // members, up to 16 of them in a pass (a member with more has its row in several
-        // passes).  The rows are sorted by falling r (a counting sort over the 63 lengths) and
+        // passes, each filling its own 16-bit slice of p's word).  The rows are sorted by falling r (a counting sort over the 63 lengths) and
         // the wavefronts draw them 64 at a time from a queue, the first pass first and the long
         // rows first: the lanes of a wavefront hold rows of nearly the same length, walk them
         // in step (next earlier member: an address increment) and leave the loop together,
@@ -1100,12 +1102,23 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                 int q = 0;
                 if (lane == 0) q = atomicAdd(&rowhist[128], 1);
                 q = __builtin_amdgcn_readfirstlane(q);
-                int pass = 0, n = n0;
-                if (q >= g0) { q -= g0; pass = 1; n = n1; }
-                if (pass == 1 && q >= g1) { q -= g1; pass = 2; n = n2; }
-                if (pass == 2 && q >= g2) { q -= g2; pass = 3; n = n3; }
-                if (pass == 3 && q >= g3) break;
-                const int w = (q << 6) + lane;
+                // Ticket -> (group, pass), group by group: group g of pass k holds rows of at most
+                // min(r(g) - 16 k, 16) members, falling in g and in k, so the long units go out first
+                // (g3 <= g2 <= g1 <= g0: the first g3 groups are in four passes, the next in three, ...).
+                int pass, g;
+                if (q < 4 * g3) { g = q >> 2; pass = q & 3; }
+                else {
+                    q -= 4 * g3;
+                    if (q < 3 * (g2 - g3)) { const int d = q / 3; g = g3 + d; pass = q - 3 * d; }
+                    else {
+                        q -= 3 * (g2 - g3);
+                        if (q < 2 * (g1 - g2)) { g = g2 + (q >> 1); pass = q & 1; }
+                        else { g = g1 + q - 2 * (g1 - g2); pass = 0; }
+                    }
+                }
+                if (g >= g0) break;
+                const int n = pass == 0 ? n0 : pass == 1 ? n1 : pass == 2 ? n2 : n3;
+                const int w = (g << 6) + lane;
                 if (w < n) {
                     const int ent = rowlist[w];
                     const int p = ent & 0xffff, rp = ent >> 16;
@@ -1113,14 +1126,26 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                     const float4 bp = sbox[p];
                     const Box later{bp.x, bp.y, bp.z, bp.w};
                     const float abp = box_area(later);
-                    const unsigned long long jbit = 1ull << rp;
                     const int base = p - rp + 16 * pass;
-                    for (int ii = 0; ii < len; ++ii) {
-                        const float4 b = sbox[base + ii];
+                    unsigned int hits = 0u;
+                    auto test = [&](const float4& b, int ii) {
                         const Box eb{b.x, b.y, b.z, b.w};
-                        if (iou_above_band_areas(eb, box_area(eb), later, abp, band))
-                            atomicOr(&kills[base + ii], jbit);
+                        hits |= (iou_above_band_areas(eb, box_area(eb), later, abp, band) ? 1u : 0u) << ii;
+                    };
+                    // two earlier members a step, each box requested a step ahead (the reads run
+                    // two positions past p at most: inside the image's LDS region, unused)
+                    float4 b0 = sbox[base], b1 = sbox[base + 1];
+                    int ii = 0;
+                    for (; ii + 1 < len; ii += 2) {
+                        const float4 c0 = b0, c1 = b1;
+                        b0 = sbox[base + ii + 2];
+                        b1 = sbox[base + ii + 3];
+                        test(c0, ii);
+                        test(c1, ii + 1);
                     }
+                    if (ii < len) test(b0, ii);
+                    // p's word, this pass's slice: the earlier members that overlap p
+                    reinterpret_cast<unsigned short*>(kills + p)[pass] = (unsigned short)hits;
                 }
             }
         }
@@ -1149,16 +1174,24 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                 if ((ent >> 16) != round) continue;
                 const int head = ent & 0xffff;
                 const int len = slen[head];
-                unsigned long long dead = 0ull;
+                // Bit j of `am`: member j stays -- or has not been reached yet.  A member's word
+                // holds the earlier members that overlap it and, when an earlier block's survivor
+                // has suppressed it, its own bit; nothing above its own bit.  So one AND with `am`
+                // tests both, and the dependent chain per member is AND, compare, select.  Words
+                // past the block's end (read without a guard: still inside the image's LDS region)
+                // only touch bits no member owns.
+                unsigned long long am = ~0ull;
                 for (int base = 0; base < len; base += 8) {
                     unsigned long long kw[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) kw[u] = base + u < len ? kills[head + base + u] : 0ull;
+                    for (int u = 0; u < 8; ++u) kw[u] = kills[head + base + u];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (!((dead >> (base + u)) & 1ull)) dead |= kw[u];
+                    for (int u = 0; u < 8; ++u) {
+                        const unsigned long long without = am & ~(1ull << (base + u));
+                        if ((kw[u] & am) != 0ull) am = without;
+                    }
                 }
-                kills[head] = dead;
+                kills[head] = ~am;                 // bit j: member j of the block is suppressed
             }
             group_sync<NT>();
             YH_STAMP(13);
@@ -1201,7 +1234,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                     const float4 mb = sbox[i];
                     const bool hit = palive && iou_above_band(pb, {mb.x, mb.y, mb.z, mb.w}, xband);
                     if (__ballot(hit) && lane == 0) {
-                        kills[i] = 0ull;     // kills nobody when its block is walked
+                        kills[i] = 1ull << ((i - (ent >> 16)) & 63);     // its own bit: gone when its block is walked
                         atomicAnd(&alive[i >> 6], ~(1ull << (i & 63)));
                     }
                 }
