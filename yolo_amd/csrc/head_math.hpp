@@ -152,6 +152,19 @@ __device__ __forceinline__ bool iou_above_band_areas(const Box& p, float a1, con
     if (!(inter > t_hi) && !(inter < t_lo)) above = (uni == 0.0f ? 0.0f : inter / uni) > band.thr;
     return above;
 }
+// The same answer with one branch region instead of two nested ones (both compares first, then
+// the lanes that are unsure divide): for loops where the test is most of the body.
+__device__ __forceinline__ bool iou_above_band_flat(const Box& p, float a1, const Box& g, float a2,
+                                                    const IouBand& band) {
+    const float iw = fmaxf(vmin_raw(p.r, g.r) - vmax_raw(p.l, g.l), 0.0f);
+    const float ih = fmaxf(vmin_raw(p.b, g.b) - vmax_raw(p.t, g.t), 0.0f);
+    const float inter = iw * ih;
+    const float uni = (a1 + a2) - inter;
+    bool above = inter > __builtin_fmaf(band.hi, uni, 1e-30f);
+    const bool unsure = !above & !(inter < __builtin_fmaf(band.lo, uni, -1e-30f));
+    if (unsure) above = (uni == 0.0f ? 0.0f : inter / uni) > band.thr;
+    return above;
+}
 __device__ __forceinline__ bool iou_above_band(const Box& p, const Box& g, const IouBand& band) {
     return iou_above_band_areas(p, box_area(p), g, box_area(g), band);
 }

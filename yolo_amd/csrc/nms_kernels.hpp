@@ -1130,20 +1130,26 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                     unsigned int hits = 0u;
                     auto test = [&](const float4& b, int ii) {
                         const Box eb{b.x, b.y, b.z, b.w};
-                        hits |= (iou_above_band_areas(eb, box_area(eb), later, abp, band) ? 1u : 0u) << ii;
+                        hits |= (iou_above_band_flat(eb, box_area(eb), later, abp, band) ? 1u : 0u) << ii;
                     };
-                    // two earlier members a step, each box requested a step ahead (the reads run
-                    // two positions past p at most: inside the image's LDS region, unused)
-                    float4 b0 = sbox[base], b1 = sbox[base + 1];
+                    // four earlier members a step; a box is requested again as soon as it has been
+                    // used, two tests before it is needed (the reads run four positions past p at
+                    // most: inside the image's LDS region, unused)
+                    float4 b0 = sbox[base], b1 = sbox[base + 1], b2 = sbox[base + 2], b3 = sbox[base + 3];
                     int ii = 0;
-                    for (; ii + 1 < len; ii += 2) {
-                        const float4 c0 = b0, c1 = b1;
-                        b0 = sbox[base + ii + 2];
-                        b1 = sbox[base + ii + 3];
-                        test(c0, ii);
-                        test(c1, ii + 1);
+                    for (; ii + 3 < len; ii += 4) {
+                        test(b0, ii);
+                        test(b1, ii + 1);
+                        b0 = sbox[base + ii + 4];
+                        b1 = sbox[base + ii + 5];
+                        test(b2, ii + 2);
+                        test(b3, ii + 3);
+                        b2 = sbox[base + ii + 6];
+                        b3 = sbox[base + ii + 7];
                     }
                     if (ii < len) test(b0, ii);
+                    if (ii + 1 < len) test(b1, ii + 1);
+                    if (ii + 2 < len) test(b2, ii + 2);
                     // p's word, this pass's slice: the earlier members that overlap p
                     reinterpret_cast<unsigned short*>(kills + p)[pass] = (unsigned short)hits;
                 }
