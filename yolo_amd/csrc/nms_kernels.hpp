@@ -303,6 +303,56 @@ __device__ __forceinline__ void nms_wave_one_per_lane(const WaveNmsTables& tb, i
 // cell is a constant offset; 0: run-time); SRC 1: candidates loaded from memory.
 // The work of workgroup `block_id` of the NMS grid; `smem` is its LDS
 // (region_bytes per image it holds).
+// Bit ii of the result: the box at sbox[base + ii] overlaps `later` (area `alater`) by more than
+// the threshold, for ii < len <= 16.  Four boxes a step; a box is requested again as soon as it has
+// been used, two tests before it is needed.  The reads run up to four positions past base + len:
+// the caller's array must be followed by readable LDS (the image's region is).
+__device__ __forceinline__ unsigned int iou_hits_run(const float4* sbox, int base, int len, const Box& later,
+                                                     float alater, const IouBand& band) {
+    unsigned int hits = 0u;
+    auto test = [&](const float4& b, int ii) {
+        const Box eb{b.x, b.y, b.z, b.w};
+        hits |= (iou_above_band_flat(eb, box_area(eb), later, alater, band) ? 1u : 0u) << ii;
+    };
+    float4 b0 = sbox[base], b1 = sbox[base + 1], b2 = sbox[base + 2], b3 = sbox[base + 3];
+    int ii = 0;
+    for (; ii + 3 < len; ii += 4) {
+        test(b0, ii);
+        test(b1, ii + 1);
+        b0 = sbox[base + ii + 4];
+        b1 = sbox[base + ii + 5];
+        test(b2, ii + 2);
+        test(b3, ii + 3);
+        b2 = sbox[base + ii + 6];
+        b3 = sbox[base + ii + 7];
+    }
+    if (ii < len) test(b0, ii);
+    if (ii + 1 < len) test(b1, ii + 1);
+    if (ii + 2 < len) test(b2, ii + 2);
+    return hits;
+}
+
+// The same with two boxes in flight instead of four (eight registers less; reads run up to two
+// positions past base + len)
+__device__ __forceinline__ unsigned int iou_hits_run2(const float4* sbox, int base, int len, const Box& later,
+                                                      float alater, const IouBand& band) {
+    unsigned int hits = 0u;
+    auto test = [&](const float4& b, int ii) {
+        const Box eb{b.x, b.y, b.z, b.w};
+        hits |= (iou_above_band_flat(eb, box_area(eb), later, alater, band) ? 1u : 0u) << ii;
+    };
+    float4 b0 = sbox[base], b1 = sbox[base + 1];
+    int ii = 0;
+    for (; ii + 1 < len; ii += 2) {
+        test(b0, ii);
+        b0 = sbox[base + ii + 2];
+        test(b1, ii + 1);
+        b1 = sbox[base + ii + 3];
+    }
+    if (ii < len) test(b0, ii);
+    return hits;
+}
+
 template <int NT, int ITEMS, int SRC, int S_CT, int BX_CT, int C_CT, bool CM = false>
 __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsigned char* smem) {
     static_assert(!CM || (S_CT == 0 && SRC == 0), "cell-major tensors take the run-time-shape path");
@@ -1127,29 +1177,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                     const Box later{bp.x, bp.y, bp.z, bp.w};
                     const float abp = box_area(later);
                     const int base = p - rp + 16 * pass;
-                    unsigned int hits = 0u;
-                    auto test = [&](const float4& b, int ii) {
-                        const Box eb{b.x, b.y, b.z, b.w};
-                        hits |= (iou_above_band_flat(eb, box_area(eb), later, abp, band) ? 1u : 0u) << ii;
-                    };
-                    // four earlier members a step; a box is requested again as soon as it has been
-                    // used, two tests before it is needed (the reads run four positions past p at
-                    // most: inside the image's LDS region, unused)
-                    float4 b0 = sbox[base], b1 = sbox[base + 1], b2 = sbox[base + 2], b3 = sbox[base + 3];
-                    int ii = 0;
-                    for (; ii + 3 < len; ii += 4) {
-                        test(b0, ii);
-                        test(b1, ii + 1);
-                        b0 = sbox[base + ii + 4];
-                        b1 = sbox[base + ii + 5];
-                        test(b2, ii + 2);
-                        test(b3, ii + 3);
-                        b2 = sbox[base + ii + 6];
-                        b3 = sbox[base + ii + 7];
-                    }
-                    if (ii < len) test(b0, ii);
-                    if (ii + 1 < len) test(b1, ii + 1);
-                    if (ii + 2 < len) test(b2, ii + 2);
+                    const unsigned int hits = iou_hits_run(sbox, base, len, later, abp, band);
                     // p's word, this pass's slice: the earlier members that overlap p
                     reinterpret_cast<unsigned short*>(kills + p)[pass] = (unsigned short)hits;
                 }
@@ -1212,9 +1240,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             if (round + 1 < nrounds) {
                 // The survivors of block `round` against the members of the later blocks of
                 // their segment (that block is full: 64 positions from its start).  The later
-                // members queue up; a wavefront takes one of them at a time, its lanes holding
-                // the 64 pivots (kept in registers while the queue stays in one segment), so a
-                // member costs one IoU test per wavefront instead of a loop over the pivots.
+                // members queue up.
                 int* xlist = sseg;           // the segment starts are dead since the pair loop
 #pragma unroll
                 for (int e = 0; e < ITEMS; ++e) {
@@ -1222,25 +1248,23 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                         xlist[atomicAdd(&misc[3], 1)] = (e * NT + t) | (mymeta[e].w << 16);
                 }
                 group_sync<NT>();
+                // A work item is a queued member against 16 of the block's 64 pivots: the run of
+                // tests of the pair phase, masked with the pivots that stayed.
                 const int nx = misc[3];
-                int cached = -1;
-                Box pb = {0.f, 0.f, 0.f, 0.f};
-                bool palive = false;
-                for (int x = wv; x < nx; x += NW) {
-                    const int ent = xlist[x];
-                    const int i = ent & 0xffff;
-                    const int base = (ent >> 16) + (round << 6);
-                    if (base != cached) {
-                        cached = base;
-                        const int pv = base + lane;
-                        const float4 b = sbox[pv];
-                        pb = {b.x, b.y, b.z, b.w};
-                        palive = (alive[pv >> 6] >> (pv & 63)) & 1ull;
-                    }
+                for (int it = t; it < 4 * nx; it += NT) {
+                    const int ent = xlist[it >> 2];
+                    const int i = ent & 0xffff, seg0 = ent >> 16;
+                    const int pb = seg0 + (round << 6) + ((it & 3) << 4);   // the chunk's first pivot
+                    const int wd = pb >> 6, sh = pb & 63;
+                    unsigned long long stay = alive[wd] >> sh;
+                    if (sh > 48) stay |= alive[wd + 1] << (64 - sh);
+                    const unsigned int stay16 = (unsigned int)stay & 0xffffu;
+                    if (stay16 == 0u) continue;
                     const float4 mb = sbox[i];
-                    const bool hit = palive && iou_above_band(pb, {mb.x, mb.y, mb.z, mb.w}, xband);
-                    if (__ballot(hit) && lane == 0) {
-                        kills[i] = 1ull << ((i - (ent >> 16)) & 63);     // its own bit: gone when its block is walked
+                    const Box later{mb.x, mb.y, mb.z, mb.w};
+                    if (iou_hits_run2(sbox, pb, 16, later, box_area(later), xband) & stay16) {
+                        // the same values whichever chunk's lane gets here
+                        kills[i] = 1ull << ((i - seg0) & 63);     // its own bit: gone when its block is walked
                         atomicAnd(&alive[i >> 6], ~(1ull << (i & 63)));
                     }
                 }
