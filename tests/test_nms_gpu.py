@@ -128,6 +128,34 @@ def test_one_class_takes_most_cells(dev, S, Bx, C):
         assert_same(got, oracle_nms(ltrb, score, cls, present, ct, it))
 
 
+@pytest.mark.parametrize("cells_a,cells_b", [(38, 39), (51, 52), (13, 64), (39, 103)])
+def test_class_buckets_around_the_ranking_switch(dev, cells_a, cells_b):
+    """The fused kernel ranks a class bucket by counting up to 192 candidates and by sorted
+    chunks of 64 plus binary searches above: two classes win exact numbers of cells (5
+    candidates each: 190 and 195, 255 and 260, 65 and 320, 195 and 515 candidates), chunks
+    that end on and next to a multiple of 64, in one image with equal scores."""
+    S, Bx, C = 14, 5, 80
+    head = YOLOv1Head(img_size=448, n_cells=S, n_bboxes=Bx, n_classes=C)
+    pred = synth.make_pred(3, S, Bx, C, seed=cells_a * 1000 + cells_b)
+    g = torch.Generator().manual_seed(cells_a + cells_b)
+    for b in range(3):
+        order = torch.randperm(S * S, generator=g)
+        flat = pred[b].view(5 * Bx + C, S * S)
+        flat[5 * Bx + 7] -= 40.0                  # these two classes win the chosen cells only
+        flat[5 * Bx + 61] -= 40.0
+        flat[5 * Bx + 7, order[:cells_a]] += 80.0
+        flat[5 * Bx + 61, order[cells_a:cells_a + cells_b]] += 80.0
+    # image 1: confidences on a coarse grid, so that many candidates tie and the index decides
+    conf = pred[1, 4:5 * Bx:5]
+    pred[1, 4:5 * Bx:5] = (conf * 2).round() / 2
+    pred = pred.to(dev)
+    ltrb, score, cls, present = head.decode_candidates(pred, MODE_DENSE)
+    assert int((cls[0] == 7).sum()) == 5 * cells_a and int((cls[0] == 61).sum()) == 5 * cells_b
+    for ct, it in ((0.001, 0.5), (0.3, 0.2)):
+        got = head.postprocess(pred, ct, it, MODE_DENSE, return_idx=True)
+        assert_same(got, oracle_nms(ltrb, score, cls, present, ct, it))
+
+
 @pytest.mark.parametrize("size", [1e-19, 3e-16, 1e-12])
 def test_boxes_whose_areas_are_denormal(dev, size):
     """Boxes of 1e-19 px have areas of 1e-38, among the denormals, where a product or a
