@@ -302,11 +302,6 @@ __device__ __forceinline__ void nms_wave_one_per_lane(const WaveNmsTables& tb, i
     if (lane == 0) *count = total;
 }
 
-// SRC 0: candidates decoded from the head tensor (S_CT, BX_CT, C_CT > 0: grid
-// size and predictor/class counts fixed at compile time, so every channel of a
-// cell is a constant offset; 0: run-time); SRC 1: candidates loaded from memory.
-// The work of workgroup `block_id` of the NMS grid; `smem` is its LDS
-// (region_bytes per image it holds).
 // Sorts the 64 keys of a wavefront, one per lane, ascending by lane: a bitonic network of 21
 // compare-exchange steps through lane shuffles, nothing in LDS.
 __device__ __forceinline__ unsigned long long wave_sort_u64(unsigned long long key, int lane) {
@@ -374,6 +369,11 @@ __device__ __forceinline__ unsigned int iou_hits_run2(const float4* sbox, int ba
     return hits;
 }
 
+// SRC 0: candidates decoded from the head tensor (S_CT, BX_CT, C_CT > 0: grid
+// size and predictor/class counts fixed at compile time, so every channel of a
+// cell is a constant offset; 0: run-time); SRC 1: candidates loaded from memory.
+// The work of workgroup `block_id` of the NMS grid; `smem` is its LDS
+// (region_bytes per image it holds).
 template <int NT, int ITEMS, int SRC, int S_CT, int BX_CT, int C_CT, bool CM = false>
 __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsigned char* smem) {
     static_assert(!CM || (S_CT == 0 && SRC == 0), "cell-major tensors take the run-time-shape path");
