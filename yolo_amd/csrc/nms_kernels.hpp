@@ -58,7 +58,7 @@ struct NmsArgs {
     float cellf, imgf, conf_thr, iou_thr;
     // per-image LDS region: byte offsets of the arrays inside it, and its size
     int off_stage;   // cell-major only: LDS copy of the image's block (-1: read from memory)
-    int off_keys, off_box, off_meta, off_seg, off_alive, off_misc, off_ccls, off_hist, off_segst, off_pair, off_kill;
+    int off_keys, off_box, off_meta, off_seg, off_alive, off_misc, off_ccls, off_hist, off_segst, off_kill;
     int region_bytes;
     int dbg_stop;  // builds with -DYH_PHASE_PROBE only: leave after this phase (0 = run everything)
     // builds with -DYH_PHASE_PROBE only: 16 time stamps per workgroup (100 MHz counter)
@@ -388,7 +388,8 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
     const int t = threadIdx.x % NT;
     const int lane = threadIdx.x & 63;
     const int wv = t >> 6;  // wavefront within the image group
-    const long long img = (long long)block_id * IPB + sub;
+    // (one image per workgroup: the image index is uniform, a scalar register pair)
+    const long long img = IPB == 1 ? (long long)block_id : (long long)block_id * IPB + sub;
     // NT == 64: a whole wavefront leaves and no workgroup barrier is used below;
     // NT == 256: the grid has exactly one workgroup per image, so this never fires.
     if (img >= a.batch) return;
@@ -1093,8 +1094,13 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                 const float4 b = sbox[i];
                 mybox[e] = {b.x, b.y, b.z, b.w};
             }
-            const int2 m = smeta[i];
-            mymeta[e] = make_int4(m.x, m.y >> 16, m.y & 0xffff, kWave ? 0 : sseg[i]);
+            if constexpr (kWave) {
+                const int2 m = smeta[i];
+                mymeta[e] = make_int4(m.x, m.y >> 16, m.y & 0xffff, 0);
+            } else {
+                // score, class and flat index stay in LDS until the survivors are written out
+                mymeta[e] = make_int4(0, 0, 0, sseg[i]);
+            }
         }
     }
     if constexpr (kWave) {
@@ -1179,9 +1185,9 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         // rows first: the lanes of a wavefront hold rows of nearly the same length, walk them
         // in step (next earlier member: an address increment) and leave the loop together,
         // and no wavefront is left with the long rows.  The row list takes the place of
-        // smeta, which every thread has read into registers before the barrier below.
-        int* rowlist = reinterpret_cast<int*>(region + a.off_pair);
-        int* slen = rowlist + NT * ITEMS;     // at a block's first position: its member count
+        // the segment starts, which every thread has read into a register before the barrier
+        // below.
+        int* rowlist = sseg;
         // [0..63] rows of length 63 - bin, [64..127] fill cursors, [128] queue head; cleared at entry
         int* rowhist = reinterpret_cast<int*>(region + a.off_kill);
         int r[ITEMS];
@@ -1192,12 +1198,9 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             const int i = e * NT + t;
             const int pos = al[e] ? i - mymeta[e].w : 0;
             r[e] = pos & 63;                      // members of my block ahead of me
-            // the block lengths go by block starts (this thread alone has read sseg[i] so far)
-            if (nrounds > 1 && al[e]) sseg[i] = i - r[e];
             if (al[e]) kills[i] = 0ull;
             if (r[e] > 0) atomicAdd(&rowhist[63 - r[e]], 1);
         }
-        if (t == 0) misc[2] = 0;   // number of block heads queued below
         group_sync<NT>();
         YH_STAMP(9);
         const int wv_s = __builtin_amdgcn_readfirstlane(wv);
@@ -1209,10 +1212,6 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             const int i = e * NT + t;
             const int first = __shfl(hex, 63 - r[e], 64);     // all lanes take part
             if (r[e] > 0) rowlist[first + atomicAdd(&rowhist[64 + 63 - r[e]], 1)] = i | (r[e] << 16);
-            if (al[e]) {
-                const int nxt = i + 1 < nvalid ? sseg[i + 1] : -1;
-                if (nxt != i - r[e]) slen[i - r[e]] = r[e] + 1;   // the block's last member
-            }
         }
         group_sync<NT>();
         YH_STAMP(10);
@@ -1266,52 +1265,69 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
 #ifdef YH_PHASE_PROBE
         if (a.dbg_stop == 6) return;
 #endif
-        // the block heads queue up in a list (any order: blocks of one round are
-        // independent), each with its block number; the pair offsets are dead by now
-        int* hlist = rowlist;
-#pragma unroll
-        for (int e = 0; e < ITEMS; ++e) {
-            const int i = e * NT + t;
-            if (al[e] && r[e] == 0) hlist[atomicAdd(&misc[2], 1)] = i | (blk(e) << 16);
-        }
-        group_sync<NT>();
         YH_STAMP(12);
-        const int nheads = misc[2];
         const IouBand xband = make_iou_band(a.iou_thr);
         for (int round = 0; round < nrounds; ++round) {
-            // one lane per block of this round: greedy pass over its members, eight words
-            // per round trip
-            for (int h = t; h < nheads; h += NT) {
-                const int ent = hlist[h];
-                if ((ent >> 16) != round) continue;
-                const int head = ent & 0xffff;
-                const int len = slen[head];
-                // Bit j of `am`: member j stays -- or has not been reached yet.  A member's word
-                // holds the earlier members that overlap it and, when an earlier block's survivor
-                // has suppressed it, its own bit; nothing above its own bit.  So one AND with `am`
-                // tests both, and the dependent chain per member is AND, compare, select.  Words
-                // past the block's end (read without a guard: still inside the image's LDS region)
-                // only touch bits no member owns.
-                unsigned long long am = ~0ull;
-                for (int base = 0; base < len; base += 8) {
-                    unsigned long long kw[8];
+            // The greedy pass over the blocks of this round, all of them at once: "a member stays
+            // iff no member that stays is in its word" is a fixed point that the 64 lanes of a
+            // wavefront reach with ballots, in as many steps as the longest chain of the image
+            // -- nothing walks a block member by member.  A wavefront holds 64 consecutive
+            // positions; a block (64 members at most) lies in one such chunk or in two.  Pass 1
+            // settles the members whose block starts in their own chunk (all their earlier
+            // members are lanes of the same wavefront), pass 2, behind a barrier, the members
+            // whose block started in the chunk before: those earlier members' fate is in that
+            // chunk's liveness word by then.  A member's own bit in its word says that an earlier
+            // block's survivor has suppressed it already.
+            bool late[ITEMS];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) kw[u] = kills[head + base + u];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const unsigned long long without = am & ~(1ull << (base + u));
-                        if ((kw[u] & am) != 0ull) am = without;
-                    }
+            for (int e = 0; e < ITEMS; ++e) {
+                const bool part = al[e] && blk(e) == round;
+                const unsigned long long w = part ? kills[e * NT + t] : 0ull;
+                const bool gone = (w >> r[e]) & 1ull;
+                const int d = r[e] - lane;          // > 0: the block started d lanes before this chunk
+                late[e] = part && !gone && d > 0;
+                if (part && gone) al[e] = false;
+                bool mine = part && !gone && d <= 0;
+                // the earlier members that overlap this one, as lanes of this chunk
+                const unsigned long long in_chunk = mine ? (w & ((1ull << r[e]) - 1ull)) << -d : 0ull;
+                unsigned long long open = __ballot(mine), kept = 0ull;
+                while (open) {
+                    const bool die = mine && (in_chunk & kept) != 0ull;
+                    const bool keep = mine && !die && (in_chunk & open) == 0ull;
+                    const unsigned long long km = __ballot(keep);
+                    kept |= km;
+                    open &= ~(km | __ballot(die));
+                    if (die) al[e] = false;
+                    if (die || keep) mine = false;
                 }
-                kills[head] = ~am;                 // bit j: member j of the block is suppressed
+                const unsigned long long lw = __ballot(al[e]);
+                if (lane == 0) alive[e * NW + wv] = lw;
             }
             group_sync<NT>();
             YH_STAMP(13);
 #pragma unroll
             for (int e = 0; e < ITEMS; ++e) {
-                if (al[e] && blk(e) == round && ((kills[e * NT + t - r[e]] >> r[e]) & 1ull)) al[e] = false;
-                const unsigned long long w = __ballot(al[e]);
-                if (lane == 0) alive[e * NW + wv] = w;
+                if (__ballot(late[e]) == 0ull) continue;       // the same for the whole wavefront
+                bool mine = late[e];
+                const int d = mine ? r[e] - lane : 1;
+                // (the word again: nothing 64 bits wide is carried over the barrier)
+                const unsigned long long earlier = mine ? kills[e * NT + t] & ((1ull << r[e]) - 1ull) : 0ull;
+                const unsigned long long in_chunk = earlier >> d;
+                const unsigned long long before_chunk = (earlier & ((1ull << d) - 1ull)) << (64 - d);
+                const unsigned long long prev = alive[e * NW + wv - 1];   // a late member is not in chunk 0
+                if (mine && (before_chunk & prev) != 0ull) { al[e] = false; mine = false; }
+                unsigned long long open = __ballot(mine), kept = 0ull;
+                while (open) {
+                    const bool die = mine && (in_chunk & kept) != 0ull;
+                    const bool keep = mine && !die && (in_chunk & open) == 0ull;
+                    const unsigned long long km = __ballot(keep);
+                    kept |= km;
+                    open &= ~(km | __ballot(die));
+                    if (die) al[e] = false;
+                    if (die || keep) mine = false;
+                }
+                const unsigned long long lw = __ballot(al[e]);
+                if (lane == 0) alive[e * NW + wv] = lw;     // this wavefront's own word
             }
             if (t == 0) misc[3] = 0;   // members queued for the test against this block's survivors
             group_sync<NT>();
@@ -1353,12 +1369,15 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
             }
         }
         YH_STAMP(14);
-        // the survivors' boxes come back from LDS along with the liveness words
+        // the survivors' boxes, scores, classes and flat indices come back from LDS along with
+        // the liveness words
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
             if (al[e]) {
                 const float4 b = sbox[e * NT + t];
+                const int2 m = smeta[e * NT + t];
                 mybox[e] = {b.x, b.y, b.z, b.w};
+                mymeta[e] = make_int4(m.x, m.y >> 16, m.y & 0xffff, mymeta[e].w);
             }
         }
         // survivors before each chunk of 64 positions: a lane per chunk, one scan per wavefront

@@ -83,9 +83,6 @@ void nms_layout(yh::NmsArgs& a, int slot_pad, int imgs_per_block = 1) {
     off += round16(a.nc * 4);
     a.off_segst = off;
     off += round16(a.nc * 4);
-    // pair offsets per position (a workgroup per image): slot_pad + 1 ints in the place of
-    // the 2 * slot_pad ints at off_meta, which are dead by then
-    a.off_pair = a.off_meta;
     // kill and precedence tables of the one-wavefront path: 2 x 64 words of 64 bits
     // (2 x 128 slots x 2 words with two candidates per lane)
     a.off_kill = off;
