@@ -28,9 +28,12 @@ namespace yh {
 
 constexpr int NMS_BLOCK = 256;
 // bucketed ranking: a class bucket up to this size is ranked by counting (n * n comparisons), a
-// larger one by sorted chunks and binary searches, whose fixed cost (a wavefront sort, two
-// barriers) pays from about 200 keys on
-constexpr int RANK_COUNT_MAX = 192;
+// larger one by chunks of 64 ranked that way plus binary searches between the chunks, whose
+// fixed cost (two barriers, the searches) pays from about 200 keys on
+#ifndef YH_RANK_COUNT_MAX
+#define YH_RANK_COUNT_MAX 192
+#endif
+constexpr int RANK_COUNT_MAX = YH_RANK_COUNT_MAX;
 // threads of a workgroup: 256, or the image's whole group when that is larger
 constexpr int nms_block_threads(int nt) { return nt > NMS_BLOCK ? nt : NMS_BLOCK; }
 
@@ -302,23 +305,6 @@ __device__ __forceinline__ void nms_wave_one_per_lane(const WaveNmsTables& tb, i
     if (lane == 0) *count = total;
 }
 
-// Sorts the 64 keys of a wavefront, one per lane, ascending by lane: a bitonic network of 21
-// compare-exchange steps through lane shuffles, nothing in LDS.
-__device__ __forceinline__ unsigned long long wave_sort_u64(unsigned long long key, int lane) {
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j >= 1; j >>= 1) {
-            const unsigned long long other = __shfl_xor(key, j, 64);
-            // runs of k lanes alternate between rising and falling (the last step: one rising
-            // run); the lower lane of a pair keeps the smaller key in a rising run
-            const bool take_min = ((lane & k) == 0) == ((lane & j) == 0);
-            if ((other < key) == take_min) key = other;
-        }
-    }
-    return key;
-}
-
 // Bit ii of the result: the box at sbox[base + ii] overlaps `later` (area `alater`) by more than
 // the threshold, for ii < len <= 16.  Four boxes a step; a box is requested again as soon as it has
 // been used, two tests before it is needed.  The reads run up to four positions past base + len:
@@ -420,7 +406,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         cbox[e] = {0.f, 0.f, 0.f, 0.f};
         cscore[e] = 0.f; ccl[e] = 0; cidx[e] = 0; cvalid[e] = false;
     }
-    if (t == 0) { misc[0] = 0; misc[1] = 0; misc[4] = 0; }   // [4]: buckets above RANK_COUNT_MAX listed (bucketed ranking)
+    if (t == 0) { misc[0] = 0; misc[1] = 0; misc[4] = 0; }   // [4]: a bucket above RANK_COUNT_MAX is there (bucketed ranking)
     if constexpr (!kWave) {
         // bins and cursors of the pair phase's row sort (the tables of the one-wavefront path lie here)
         if (t < 160) reinterpret_cast<int*>(region + a.off_kill)[t] = 0;
@@ -954,75 +940,74 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         // wavefronts busy, not every wavefront of the image.  The rank goes back to the
         // candidate's owner through LDS (the slot index is in the key).
         int* rankof = sseg;                       // not written before phase C
-        int* biglist = reinterpret_cast<int*>(alive);   // classes with more than RANK_COUNT_MAX keys; alive is phase D's
         const int nbucketed = segst[nc - 1] + hist[nc - 1];
+        // A bucket of n > RANK_COUNT_MAX keys would cost n * n comparisons that way.  Its keys are
+        // ranked inside their chunk of 64 here (the same counting loop), written back in that
+        // order, and a key's rank is then its place in its own chunk plus, for every other chunk,
+        // the number of smaller keys there -- a binary search of seven steps, the chunks'
+        // searches in step.
+        unsigned long long bigkey[ITEMS];     // a key of such a bucket ...
+        int bigpos[ITEMS];                    // ... and its position in chunk order (-1: none)
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
             const int p = e * NT + t;
+            bigpos[e] = -1;
+            bigkey[e] = 0ull;
             if (p < nbucketed) {
                 const unsigned long long kp = keys[p];
                 const int c = (int)(kp >> 48);
                 const int s0 = segst[c];
                 const int n = hist[c];
-                const int ncount = n <= RANK_COUNT_MAX ? n : 0;     // a larger bucket is ranked below
+                const bool big = n > RANK_COUNT_MAX;
+                const int first = big ? s0 + ((p - s0) & ~63) : s0;           // of the keys counted here
+                const int ncount = big ? min(64, s0 + n - first) : n;
                 int cnt = 0;
-                for (int j = 0; j < ncount; ++j) cnt += keys[s0 + j] < kp ? 1 : 0;
-                if (n <= RANK_COUNT_MAX) rankof[(int)(kp & 0xffffull)] = s0 + cnt;
-                else if (p == s0) biglist[atomicAdd(&misc[4], 1)] = c;
+                for (int j = 0; j < ncount; ++j) cnt += keys[first + j] < kp ? 1 : 0;
+                if (!big) rankof[(int)(kp & 0xffffull)] = s0 + cnt;
+                else {
+                    bigkey[e] = kp;
+                    bigpos[e] = first + cnt;
+                    if (p == s0) misc[4] = 1;
+                }
             }
         }
         group_sync<NT>();
-        const int nbig = misc[4];
-        if (nbig > 0) {    // the same for every thread of the image
-            // A bucket of n > RANK_COUNT_MAX keys would cost n * n comparisons that way.  Instead its chunks
-            // of 64 keys are sorted, a chunk per wavefront, in registers (a bitonic network over
-            // the lanes); a key's rank is then its place in its own chunk plus, for every other
-            // chunk, the number of smaller keys there -- a binary search of seven steps, four
-            // chunks' searches in step.
-            const int wv_u = __builtin_amdgcn_readfirstlane(wv);
-            int chunk_no = 0;
-            for (int k = 0; k < nbig; ++k) {
-                const int c = biglist[k];
-                const int s0 = segst[c], n = hist[c];
-                for (int cb = 0; cb < n; cb += 64, ++chunk_no) {
-                    if (chunk_no % NW != wv_u) continue;
-                    const bool in = cb + lane < n;
-                    const unsigned long long sorted = wave_sort_u64(in ? keys[s0 + cb + lane] : ~0ull, lane);
-                    if (in) keys[s0 + cb + lane] = sorted;     // all-ones words end up behind the keys
-                }
-            }
+        if (misc[4] != 0) {    // the same for every thread of the image
+#pragma unroll
+            for (int e = 0; e < ITEMS; ++e)
+                if (bigpos[e] >= 0) keys[bigpos[e]] = bigkey[e];
             group_sync<NT>();
-            for (int k = 0; k < nbig; ++k) {
-                const int c = biglist[k];
+#pragma unroll
+            for (int e = 0; e < ITEMS; ++e) {
+                if (bigpos[e] < 0) continue;
+                const unsigned long long kp = bigkey[e];
+                const int c = (int)(kp >> 48);
                 const int s0 = segst[c], n = hist[c];
                 const int nch = (n + 63) >> 6;
-                for (int j = t; j < n; j += NT) {
-                    const unsigned long long kp = keys[s0 + j];
-                    const int own = j >> 6;
-                    int rk = s0 + (j & 63);
-                    for (int q0 = 0; q0 < nch; q0 += 4) {
-                        int lo[4], m[4], base[4];
+                const int own = (bigpos[e] - s0) >> 6;
+                int rk = s0 + ((bigpos[e] - s0) & 63);
+                for (int q0 = 0; q0 < nch; q0 += 4) {
+                    int lo[4], m[4], base[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int q = q0 + u;
-                            lo[u] = 0;
-                            base[u] = s0 + 64 * q - 1;
-                            m[u] = (q < nch && q != own) ? min(64, n - 64 * q) : 0;
-                        }
-#pragma unroll
-                        for (int step = 64; step >= 1; step >>= 1) {
-                            unsigned long long kv[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                kv[u] = lo[u] + step <= m[u] ? keys[base[u] + lo[u] + step] : ~0ull;
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if (kv[u] < kp) lo[u] += step;
-                        }
-                        rk += (lo[0] + lo[1]) + (lo[2] + lo[3]);
+                    for (int u = 0; u < 4; ++u) {
+                        const int q = q0 + u;
+                        lo[u] = 0;
+                        base[u] = s0 + 64 * q - 1;
+                        m[u] = (q < nch && q != own) ? min(64, n - 64 * q) : 0;
                     }
-                    rankof[(int)(kp & 0xffffull)] = rk;
+#pragma unroll
+                    for (int step = 64; step >= 1; step >>= 1) {
+                        unsigned long long kv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            kv[u] = lo[u] + step <= m[u] ? keys[base[u] + lo[u] + step] : ~0ull;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (kv[u] < kp) lo[u] += step;
+                    }
+                    rk += (lo[0] + lo[1]) + (lo[2] + lo[3]);
                 }
+                rankof[(int)(kp & 0xffffull)] = rk;
             }
             group_sync<NT>();
         }
