@@ -234,6 +234,127 @@ __device__ __forceinline__ void loss_obj_cell(const L& logit, float* __restrict_
     acc_cls += l2;
 }
 
+// The box and confidence work of loss_obj_cell (PART 1) for a cell with TWO predictors, by a
+// pair of neighbouring lanes: lane parity k = the predictor the lane owns (its five logits
+// `logit5(0..4)`, its IoU with the ground truth, its five gradients at g[u * S2]).  The two
+// IoUs -- the long part of the path -- are formed side by side and meet through one lane
+// swap; the responsible lane then carries the coordinate and objectness terms, the other the
+// no-object term.  Same arithmetic per value as loss_obj_cell.  Both lanes of a pair must call.
+template <class L>
+__device__ __forceinline__ void loss_obj_cell_box_pair(const L& logit5, float* __restrict__ g,
+                                                       const float* __restrict__ gxywh, int cell, int S,
+                                                       int S2, int k, float cellf, float imgf, float lc,
+                                                       float ln, float inv_gb, float& acc_coord,
+                                                       float& acc_conf) {
+    const float4 gv = *reinterpret_cast<const float4*>(gxywh);
+    const float gnx = gv.x, gny = gv.y, gnw = gv.z, gnh = gv.w;
+    const float xoff = cellf * (float)(cell / S);   // first spatial axis carries x (model.py:175-177)
+    const float yoff = cellf * (float)(cell % S);
+    const Box gbox = decode_box(gnx, gny, gnw, gnh, xoff, yoff, cellf, imgf);
+    const float bnx = sigmoidf_(logit5(0));
+    const float bny = sigmoidf_(logit5(1));
+    const float bnw = sigmoidf_(logit5(2));
+    const float bnh = sigmoidf_(logit5(3));
+    float ul, ut, ur, ub;
+    const Box pb = decode_box(bnx, bny, bnw, bnh, xoff, yoff, cellf, imgf, ul, ut, ur, ub);
+    const float biou = iou_pair(pb, gbox);
+    // the neighbour's IoU (lanes 2i and 2i+1 swap)
+    const float other =
+        __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(biou), 0xB1, 0xF, 0xF, true));
+    // responsible predictor: highest IoU, first index on ties (model.py:210): predictor 1 iff
+    // its IoU is greater
+    const bool one_wins = k == 0 ? other > biou : biou > other;
+    const bool best = (k == 1) == one_wins;
+    const float conf = sigmoidf_(logit5(4));
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, gc;
+    if (best) {
+        // gradients of the responsible predictor's box (model.py:224-240, 267-269)
+        const float dx = bnx - gnx, dy = bny - gny;
+        const float sw = __builtin_amdgcn_sqrtf(bnw), sh = __builtin_amdgcn_sqrtf(bnh);
+        const float dw = sw - __builtin_amdgcn_sqrtf(gnw), dh = sh - __builtin_amdgcn_sqrtf(gnh);
+        acc_coord += lc * ((dx * dx + dy * dy) + (dw * dw + dh * dh));
+        const float r0 = 2.0f * lc * dx;
+        const float r1 = 2.0f * lc * dy;
+        const float r2 = lc * dw * sw * (1.0f - bnw);
+        const float r3 = lc * dh * sh * (1.0f - bnh);
+        // objectness term; IoU is part of the graph (model.py:263-269)
+        const float dc = conf - biou;
+        acc_conf += dc * dc;
+        float gl, gt, gr, gb;
+        iou_pair_bwd(pb, gbox, -2.0f * dc, gl, gt, gr, gb);
+        // xywh_to_ltrb backward: a clipped edge passes nothing
+        gl = ul >= 0.0f ? gl : 0.0f;
+        gt = ut >= 0.0f ? gt : 0.0f;
+        gr = ur <= imgf ? gr : 0.0f;
+        gb = ub <= imgf ? gb : 0.0f;
+        const float gx_iou = (gl + gr) * cellf;
+        const float gy_iou = (gt + gb) * cellf;
+        const float gw_iou = (gr - gl) * 0.5f * imgf;
+        const float gh_iou = (gb - gt) * 0.5f * imgf;
+        g0 = (r0 + gx_iou) * (bnx * (1.0f - bnx));
+        g1 = (r1 + gy_iou) * (bny * (1.0f - bny));
+        g2 = r2 + gw_iou * (bnw * (1.0f - bnw));
+        g3 = r3 + gh_iou * (bnh * (1.0f - bnh));
+        gc = 2.0f * dc * (conf * (1.0f - conf));
+    } else {
+        // the other predictor of the cell carries the no-object term (model.py:270-274)
+        acc_conf += ln * (conf * conf);
+        gc = 2.0f * ln * conf * (conf * (1.0f - conf));
+    }
+    g[0 * S2] = g0 * inv_gb;
+    g[1 * S2] = g1 * inv_gb;
+    g[2 * S2] = g2 * inv_gb;
+    g[3 * S2] = g3 * inv_gb;
+    g[4 * S2] = gc * inv_gb;
+}
+
+// The class work of loss_obj_cell (PART 2) by a QUAD of neighbouring lanes, C_CT / 4 classes
+// each (lane q of the quad: classes q C_CT/4 ...; `logitc(u)`, `gtc(u)`, g[u * S2]: the u-th of
+// them): the twenty exponentials of a C=20 cell become five per lane; maximum, sum and the
+// dot product meet through two lane swaps each (the same value in all four lanes: a + b is
+// b + a).  The sums are formed per lane first, so they differ from loss_obj_cell's in the last
+// bits.  All four lanes of a quad must call.
+template <int C_CT, class L, class G>
+__device__ __forceinline__ void loss_obj_cell_cls_quad(const L& logitc, const G& gtc, float* __restrict__ g,
+                                                       int S2, float inv_gb, float& acc_cls) {
+    static_assert(C_CT % 4 == 0, "a quarter of the classes per lane");
+    constexpr int N = C_CT / 4;
+    auto swap1 = [](float x) {   // lanes 4i+{0,1,2,3} <- {1,0,3,2}
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
+    };
+    auto swap2 = [](float x) {   // <- {2,3,0,1}
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));
+    };
+    float m = logitc(0);
+#pragma unroll
+    for (int u = 1; u < N; ++u) m = fmaxf(m, logitc(u));
+    m = fmaxf(m, swap1(m));
+    m = fmaxf(m, swap2(m));
+    float e[N];
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        e[u] = exp_fast(logitc(u) - m);
+        s += e[u];
+    }
+    s += swap1(s);
+    s += swap2(s);
+    const float rs = rcp_fast(s);
+    float dot = 0.f, l2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        e[u] *= rs;
+        const float d = e[u] - gtc(u);
+        l2 += d * d;
+        dot += 2.0f * d * e[u];
+    }
+    dot += swap1(dot);
+    dot += swap2(dot);
+#pragma unroll
+    for (int u = 0; u < N; ++u) g[u * S2] = e[u] * (2.0f * (e[u] - gtc(u)) - dot) * inv_gb;
+    acc_cls += l2;
+}
+
 // The same cell, worked on by a group of GW lanes (16 or 32: four or two cells per
 // wavefront at a time, for up to 4 GW classes; 64: a whole wavefront), for run-time predictor
 // and class counts: lane k < nb of the group owns predictor k (its five logits,
@@ -923,8 +1044,11 @@ constexpr int loss_tile_floats() {
 // behind pass 1.  `olist` holds the listed cells (item = image-in-workgroup * S*S + cell)
 // per wavefront, 64 entries each and in ascending item order, `wcount` their number per
 // wavefront; the j0-th listed cell of the workgroup is worked on by thread j0 (box and
-// confidence work) and by thread LOSS_THREADS/2 + j0 (class work): two wavefronts share what
-// would be one long path.  The cell's logits wait in the tile slots its gradients then take
+// confidence work; with two predictors by threads 2 j0 and 2 j0 + 1, a predictor each) and by
+// thread LOSS_THREADS/2 + j0 (class work; with two predictors and a class count divisible by
+// four by threads LOSS_THREADS/2 + 4 j0 + q, a quarter of the classes each): several lanes
+// share what would be one long path.
+// The cell's logits wait in the tile slots its gradients then take
 // (`tile` = the tile's first float of the workgroup's block).  `gt(w, j, tcell, gx, gc)` sets
 // the addresses of the cell's ground-truth box and class row, given the wavefront whose list
 // holds it, its position there and its cell index in the batch.
@@ -941,6 +1065,60 @@ __device__ __forceinline__ void loss_pass2(const int* olist, const int* wcount, 
     for (int q = 0; q < LOSS_THREADS / 64; ++q) { cnt[q] = wcount[q]; total_obj += cnt[q]; }
     constexpr int HALF = LOSS_THREADS / 2;
     const bool cls_role = (int)threadIdx.x >= HALF;
+    if constexpr (BX == 2) {
+        // Two predictors: the box work of a cell goes to a PAIR of lanes, a predictor each
+        // (loss_obj_cell_box_pair) -- thread 2 j0 + k for predictor k of the j0-th listed cell.
+        if (!cls_role) {
+            const int k = (int)threadIdx.x & 1;
+            for (int j0 = (int)threadIdx.x >> 1; j0 < total_obj; j0 += HALF / 2) {
+                int j = j0;
+                int src = 0;
+#pragma unroll
+                for (int q = 0; q < LOSS_THREADS / 64 - 1; ++q)
+                    if (src == q && j >= cnt[q]) { j -= cnt[q]; src = q + 1; }
+                const int item = olist[src * 64 + j];
+                const int gi = item / S2;
+                const int cell = item - gi * S2;
+                const long long tcell = (img0 + gi) * S2 + cell;
+                float* gl = tile + gi * (D * S2) + cell + (5 * k) * S2;
+                float v5[5];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) v5[u] = gl[u * S2];
+                auto logit5 = [&](int u) -> float { return v5[u]; };
+                const float *gx, *gc;
+                gt(src, j, tcell, gx, gc);
+                loss_obj_cell_box_pair(logit5, gl, gx, cell, S, S2, k, cellf, imgf, lc, ln, inv_gb, acc_coord,
+                                       acc_conf);
+            }
+            return;
+        }
+        if constexpr (C % 4 == 0) {
+            // ... and the class work to a QUAD of lanes, a quarter of the classes each
+            // (loss_obj_cell_cls_quad): thread HALF + 4 j0 + q
+            constexpr int N = C / 4;
+            const int q4 = (int)threadIdx.x & 3;
+            for (int j0 = ((int)threadIdx.x - HALF) >> 2; j0 < total_obj; j0 += HALF / 4) {
+                int j = j0;
+                int src = 0;
+#pragma unroll
+                for (int q = 0; q < LOSS_THREADS / 64 - 1; ++q)
+                    if (src == q && j >= cnt[q]) { j -= cnt[q]; src = q + 1; }
+                const int item = olist[src * 64 + j];
+                const int gi = item / S2;
+                const int cell = item - gi * S2;
+                const long long tcell = (img0 + gi) * S2 + cell;
+                float* gl = tile + gi * (D * S2) + cell + (5 * BX + N * q4) * S2;
+                const float *gx, *gc;
+                gt(src, j, tcell, gx, gc);
+                float vc[N], tc[N];
+#pragma unroll
+                for (int u = 0; u < N; ++u) { vc[u] = gl[u * S2]; tc[u] = gc[N * q4 + u]; }
+                loss_obj_cell_cls_quad<C>([&](int u) -> float { return vc[u]; },
+                                          [&](int u) -> float { return tc[u]; }, gl, S2, inv_gb, acc_cls);
+            }
+            return;
+        }
+    }
     for (int j0 = (int)threadIdx.x - (cls_role ? HALF : 0); j0 < total_obj; j0 += HALF) {
         int j = j0;
         int src = 0;
