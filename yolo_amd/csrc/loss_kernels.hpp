@@ -308,53 +308,6 @@ __device__ __forceinline__ void loss_obj_cell_box_pair(const L& logit5, float* _
     g[4 * S2] = gc * inv_gb;
 }
 
-// The class work of loss_obj_cell (PART 2) by a QUAD of neighbouring lanes, C_CT / 4 classes
-// each (lane q of the quad: classes q C_CT/4 ...; `logitc(u)`, `gtc(u)`, g[u * S2]: the u-th of
-// them): the twenty exponentials of a C=20 cell become five per lane; maximum, sum and the
-// dot product meet through two lane swaps each (the same value in all four lanes: a + b is
-// b + a).  The sums are formed per lane first, so they differ from loss_obj_cell's in the last
-// bits.  All four lanes of a quad must call.
-template <int C_CT, class L, class G>
-__device__ __forceinline__ void loss_obj_cell_cls_quad(const L& logitc, const G& gtc, float* __restrict__ g,
-                                                       int S2, float inv_gb, float& acc_cls) {
-    static_assert(C_CT % 4 == 0, "a quarter of the classes per lane");
-    constexpr int N = C_CT / 4;
-    auto swap1 = [](float x) {   // lanes 4i+{0,1,2,3} <- {1,0,3,2}
-        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
-    };
-    auto swap2 = [](float x) {   // <- {2,3,0,1}
-        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));
-    };
-    float m = logitc(0);
-#pragma unroll
-    for (int u = 1; u < N; ++u) m = fmaxf(m, logitc(u));
-    m = fmaxf(m, swap1(m));
-    m = fmaxf(m, swap2(m));
-    float e[N];
-    float s = 0.f;
-#pragma unroll
-    for (int u = 0; u < N; ++u) {
-        e[u] = exp_fast(logitc(u) - m);
-        s += e[u];
-    }
-    s += swap1(s);
-    s += swap2(s);
-    const float rs = rcp_fast(s);
-    float dot = 0.f, l2 = 0.f;
-#pragma unroll
-    for (int u = 0; u < N; ++u) {
-        e[u] *= rs;
-        const float d = e[u] - gtc(u);
-        l2 += d * d;
-        dot += 2.0f * d * e[u];
-    }
-    dot += swap1(dot);
-    dot += swap2(dot);
-#pragma unroll
-    for (int u = 0; u < N; ++u) g[u * S2] = e[u] * (2.0f * (e[u] - gtc(u)) - dot) * inv_gb;
-    acc_cls += l2;
-}
-
 // The same cell, worked on by a group of GW lanes (16 or 32: four or two cells per
 // wavefront at a time, for up to 4 GW classes; 64: a whole wavefront), for run-time predictor
 // and class counts: lane k < nb of the group owns predictor k (its five logits,
@@ -1045,9 +998,7 @@ constexpr int loss_tile_floats() {
 // per wavefront, 64 entries each and in ascending item order, `wcount` their number per
 // wavefront; the j0-th listed cell of the workgroup is worked on by thread j0 (box and
 // confidence work; with two predictors by threads 2 j0 and 2 j0 + 1, a predictor each) and by
-// thread LOSS_THREADS/2 + j0 (class work; with two predictors and a class count divisible by
-// four by threads LOSS_THREADS/2 + 4 j0 + q, a quarter of the classes each): several lanes
-// share what would be one long path.
+// thread LOSS_THREADS/2 + j0 (class work): several lanes share what would be one long path.
 // The cell's logits wait in the tile slots its gradients then take
 // (`tile` = the tile's first float of the workgroup's block).  `gt(w, j, tcell, gx, gc)` sets
 // the addresses of the cell's ground-truth box and class row, given the wavefront whose list
@@ -1089,32 +1040,6 @@ __device__ __forceinline__ void loss_pass2(const int* olist, const int* wcount, 
                 gt(src, j, tcell, gx, gc);
                 loss_obj_cell_box_pair(logit5, gl, gx, cell, S, S2, k, cellf, imgf, lc, ln, inv_gb, acc_coord,
                                        acc_conf);
-            }
-            return;
-        }
-        if constexpr (C % 4 == 0) {
-            // ... and the class work to a QUAD of lanes, a quarter of the classes each
-            // (loss_obj_cell_cls_quad): thread HALF + 4 j0 + q
-            constexpr int N = C / 4;
-            const int q4 = (int)threadIdx.x & 3;
-            for (int j0 = ((int)threadIdx.x - HALF) >> 2; j0 < total_obj; j0 += HALF / 4) {
-                int j = j0;
-                int src = 0;
-#pragma unroll
-                for (int q = 0; q < LOSS_THREADS / 64 - 1; ++q)
-                    if (src == q && j >= cnt[q]) { j -= cnt[q]; src = q + 1; }
-                const int item = olist[src * 64 + j];
-                const int gi = item / S2;
-                const int cell = item - gi * S2;
-                const long long tcell = (img0 + gi) * S2 + cell;
-                float* gl = tile + gi * (D * S2) + cell + (5 * BX + N * q4) * S2;
-                const float *gx, *gc;
-                gt(src, j, tcell, gx, gc);
-                float vc[N], tc[N];
-#pragma unroll
-                for (int u = 0; u < N; ++u) { vc[u] = gl[u * S2]; tc[u] = gc[N * q4 + u]; }
-                loss_obj_cell_cls_quad<C>([&](int u) -> float { return vc[u]; },
-                                          [&](int u) -> float { return tc[u]; }, gl, S2, inv_gb, acc_cls);
             }
             return;
         }
