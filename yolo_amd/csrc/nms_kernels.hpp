@@ -15,9 +15,10 @@
 //      Liveness is one 64-bit ballot per 64 positions, held in scalar registers
 //      and rebuilt after every step, so a pivot's bit is final before it is
 //      used; the loop ends when no live candidate has a pivot left.  One
-//      workgroup per image: every (earlier, later) pair of every segment is
-//      tested once, the pairs spread evenly over the threads, and a lane per
-//      segment then resolves the kill sets in order (see the code).
+//      workgroup per image: every (earlier, later) pair inside a block of 64
+//      members of a segment is tested once, the pairs spread evenly over the
+//      threads, and the blocks are then settled by a fixed point that the lanes
+//      of a wavefront reach with ballots (see the code).
 //   E  kept rows get their output slot from a prefix popcount over the
 //      liveness words and are stored straight from registers (consecutive
 //      survivors write consecutive 24-byte rows); the tail is zero-filled.
@@ -1154,13 +1155,13 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
         // spread evenly over the threads, whatever the block lengths; a pair whose IoU
         // exceeds the threshold sets bit (index of i in the block) in the word of p -- the
         // word belongs to the lane that tests p's pairs, so it is filled with plain stores.
-        // One lane per block then walks its members in order: a member stays when no member
-        // that stayed before it is in its word.  No barrier per member, and every lane of the
-        // pair loop has work.  A segment of more than 64 members takes a round per block:
-        // after the walk of its k-th block the members of the later blocks test themselves
-        // against that block's survivors (a member suppressed this way gets its OWN bit set
-        // in its word, which the walk of its block reads as "gone").  Most images need one
-        // round.
+        // The blocks are then settled: a member stays when no member that stays is in its
+        // word (a fixed point, reached with ballots -- see below).  No barrier per member, and
+        // every lane of the pair loop has work.  A segment of more than 64 members takes a
+        // round per block: after its k-th block is settled the members of the later blocks
+        // test themselves against that block's survivors (a member suppressed this way gets
+        // its OWN bit set in its word, which reads as "gone" when its block's turn comes).
+        // Most images need one round.
         const int nrounds = (maxpos >> 6) + 1;
         unsigned long long* kills = keys;     // the keys are not needed any more
         // The pair phase works on ROWS: a later member p of a block against its r earlier
@@ -1343,7 +1344,7 @@ __device__ __forceinline__ void nms_block(const NmsArgs& a, int block_id, unsign
                     const Box later{mb.x, mb.y, mb.z, mb.w};
                     if (iou_hits_run2(sbox, pb, 16, later, box_area(later), xband) & stay16) {
                         // the same values whichever chunk's lane gets here
-                        kills[i] = 1ull << ((i - seg0) & 63);     // its own bit: gone when its block is walked
+                        kills[i] = 1ull << ((i - seg0) & 63);     // its own bit: gone when its block's turn comes
                         atomicAnd(&alive[i >> 6], ~(1ull << (i & 63)));
                     }
                 }
